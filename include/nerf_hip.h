@@ -1,0 +1,113 @@
+/*
+ * nerf_hip.h — C ABI of libnerf_hip.so, the MI355X (gfx950) volume-render hot path.
+ *
+ * The reference (brandontrabucco/nerf) has no FFI of its own: its renderer is the Python
+ * method surface of nerf.model.NeRF (generation C).  Each entry point below replaces the body
+ * of one of those methods; the Python mirror in nerf_amd/model.py keeps the reference's
+ * signatures and forwards here through ctypes (see INTEGRATION.md for the binding a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch-ROCm's
+ *     caching allocator in practice); the library neither frees nor retains them;
+ *   - all tensors are fp32, row-major, contiguous;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, re-entrant,
+ *     and never synchronise the device;
+ *   - every call returns 0 on success or a negative NERF_HIP_E* code (never throws);
+ *     nerf_hip_last_error() gives a thread-local message for the last failure.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_HIP_ABI_VERSION 1
+
+#define NERF_HIP_OK 0
+#define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
+#define NERF_HIP_EUNSUPPORTED (-2) /* network shape other than the compiled-in one     */
+#define NERF_HIP_EHIP (-3)     /* a HIP runtime call failed; see nerf_hip_last_error() */
+
+/* Network shape compiled into the kernels: the constructor defaults of
+ * nerf/model.py:471-475 (hidden 256, encoding_size 32 -> 96 inputs, 1+3+50 outputs). */
+#define NERF_HIP_HIDDEN 256
+#define NERF_HIP_ENC_INPUTS 96
+#define NERF_HIP_OUTPUTS 54
+#define NERF_HIP_NUM_PARAM_TENSORS 22
+
+/* ABI version of the loaded library (NERF_HIP_ABI_VERSION at build time). */
+int nerf_hip_version(void);
+
+/* Message for the most recent failing call on this thread ("" if none). */
+const char* nerf_hip_last_error(void);
+
+/* Size in bytes of the packed parameter image consumed by the render kernels. */
+size_t nerf_hip_packed_bytes(void);
+
+/*
+ * Re-lay the 22 parameter tensors of NeRF.prediction_heads (nerf/model.py:525-542) into the
+ * MFMA-fragment / LDS-image order the kernels stream.  `params` is a HOST array of 22 DEVICE
+ * pointers in state_dict order:
+ *   prediction_heads.{0.weight[256,96], 0.bias, 1.weight, 1.bias, 3.weight[256,256], 3.bias,
+ *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[54,256], 15.bias[54]}
+ * Must be called again whenever the parameters change (once per optimiser step).
+ */
+int nerf_hip_pack_weights(const float* const* params, float* packed, void* stream);
+
+/* Where rays come from and what is written; replaces the bodies of
+ * NeRF.render_rays (nerf/model.py:596-668) and NeRF.render_image (:670-770). */
+typedef struct NerfHipRenderArgs {
+    /* --- rays: either explicit arrays ... (render_rays, model.py:596) */
+    const float* rays_o;        /* [n_rays,3] or NULL to generate from the cameras below   */
+    const float* rays_d;        /* [n_rays,3] or NULL                                      */
+    /* --- ... or generated on the fly from pinhole cameras (render_image, model.py:727-751):
+     * global ray id r = ray_begin + i, image b = r / (H*W), row = (r / W) % H, col = r % W   */
+    const float* camera_o;      /* [B,3]                                                   */
+    const float* camera_r;      /* [B,3,3]                                                 */
+    int32_t image_h, image_w;
+    float focal_length;         /* of render_image's argument (model.py:276-277)           */
+    int64_t ray_begin;          /* first global ray id of this call (row-block sharding)    */
+    int64_t n_rays;             /* rays rendered by this call                              */
+    /* --- sampling (sample_along_rays, model.py:369-435) */
+    int32_t num_samples;        /* S fenceposts -> S-1 evaluated intervals; 2 <= S <= 4096 */
+    const float* t_table;       /* [S] unscaled log-spaced fenceposts 2^linspace(...)      */
+    float t_scale;              /* |rays_max - rays_min| (model.py:435)                    */
+    const float* t_values;      /* [n_rays,S] explicit fenceposts (the `samples` argument of
+                                   NeRF.forward, model.py:553); overrides table/u if set   */
+    const float* u;             /* [n_rays,S] uniform draws of model.py:432, or NULL       */
+    const float* noise;         /* [n_rays,S-1] normal draws of model.py:652, or NULL      */
+    float density_noise_std;
+    int32_t rng_mode;           /* bit0: draw u in-kernel (Philox) when u==NULL;
+                                   bit1: draw noise in-kernel when noise==NULL            */
+    uint64_t rng_seed, rng_offset;
+    /* --- network */
+    float base_radius_sq;       /* (1/(sqrt(3)*focal))^2 with the CONSTRUCTOR focal (:546) */
+    const float* packed;        /* image written by nerf_hip_pack_weights                  */
+    /* --- outputs */
+    float* rgb;                 /* [n_rays,3]  sum_s w_s * sigmoid(color_s)   (model.py:660)*/
+    float* seg;                 /* [n_rays,50] log-probabilities (model.py:661-663) or NULL*/
+    /* optional per-sample outputs of NeRF.forward (model.py:553-594), any may be NULL      */
+    float* out_mean;            /* [n_rays,S-1,3]                                          */
+    float* out_raw;             /* [n_rays,S-1,54] density | color | segmentation logits   */
+    float* out_weights;         /* [n_rays,S-1] compositing weights (model.py:438-469)     */
+} NerfHipRenderArgs;
+
+/* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional
+ * encoding -> 6-layer MLP on fp32 MFMA -> alpha compositing.  One persistent launch. */
+int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream);
+
+/* Average duration in milliseconds of the render kernel over the launches issued since the
+ * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
+ * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */
+int nerf_hip_timing(int enable);
+int nerf_hip_timing_read(int reset, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libnerf_hip.so (C ABI: include/nerf_hip.h).
+
+There is no fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnerf_hip.so")
+ABI_VERSION = 1
+NUM_PARAM_TENSORS = 22
+
+_f32p = ctypes.c_void_p
+
+
+class RenderArgs(ctypes.Structure):
+    """Mirror of NerfHipRenderArgs (include/nerf_hip.h)."""
+    _fields_ = [
+        ("rays_o", _f32p), ("rays_d", _f32p),
+        ("camera_o", _f32p), ("camera_r", _f32p),
+        ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32),
+        ("focal_length", ctypes.c_float),
+        ("ray_begin", ctypes.c_int64), ("n_rays", ctypes.c_int64),
+        ("num_samples", ctypes.c_int32),
+        ("t_table", _f32p), ("t_scale", ctypes.c_float),
+        ("t_values", _f32p), ("u", _f32p), ("noise", _f32p),
+        ("density_noise_std", ctypes.c_float),
+        ("rng_mode", ctypes.c_int32),
+        ("rng_seed", ctypes.c_uint64), ("rng_offset", ctypes.c_uint64),
+        ("base_radius_sq", ctypes.c_float),
+        ("packed", _f32p),
+        ("rgb", _f32p), ("seg", _f32p),
+        ("out_mean", _f32p), ("out_raw", _f32p), ("out_weights", _f32p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). nerf_amd has no CPU or PyTorch fallback.")
+    handle = ctypes.CDLL(LIB_PATH)
+    handle.nerf_hip_version.restype = ctypes.c_int
+    handle.nerf_hip_last_error.restype = ctypes.c_char_p
+    handle.nerf_hip_packed_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_pack_weights.restype = ctypes.c_int
+    handle.nerf_hip_pack_weights.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
+                                             ctypes.c_void_p]
+    handle.nerf_hip_render_forward.restype = ctypes.c_int
+    handle.nerf_hip_render_forward.argtypes = [ctypes.POINTER(RenderArgs), ctypes.c_void_p]
+    handle.nerf_hip_timing.restype = ctypes.c_int
+    handle.nerf_hip_timing.argtypes = [ctypes.c_int]
+    handle.nerf_hip_timing_read.restype = ctypes.c_int
+    handle.nerf_hip_timing_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_int64)]
+    if handle.nerf_hip_version() != ABI_VERSION:
+        raise RuntimeError(f"libnerf_hip.so ABI {handle.nerf_hip_version()} != expected {ABI_VERSION}")
+    _lib = handle
+    return _lib
+
+
+EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_packed_bytes",
+           "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_timing",
+           "nerf_hip_timing_read")
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().nerf_hip_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def timing(enable):
+    check(lib().nerf_hip_timing(1 if enable else 0), "nerf_hip_timing")
+
+
+def timing_read(reset=True):
+    """(average render-kernel ms, launches) since the last reset; HIP events on the launch stream."""
+    avg, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(lib().nerf_hip_timing_read(1 if reset else 0, ctypes.byref(avg), ctypes.byref(n)),
+          "nerf_hip_timing_read")
+    return avg.value, n.value

@@ -1,0 +1,162 @@
+// Host-side helpers of the C ABI (error text, HIP-event timing) and the counter-based RNG the
+// kernels use for the in-kernel stochastic path.
+#ifndef NERF_COMMON_H
+#define NERF_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <mutex>
+#include <vector>
+
+#include "nerf_hip.h"
+
+namespace nerf_common {
+
+inline char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+inline const char* last_error() { return error_buffer(); }
+
+inline int fail(int code, const char* what) {
+    snprintf(error_buffer(), 512, "%s", what);
+    return code;
+}
+
+inline int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return NERF_HIP_OK;
+    snprintf(error_buffer(), 512, "%s: %s", what, hipGetErrorString(e));
+    return NERF_HIP_EHIP;
+}
+
+// Kernel timing with HIP events recorded on the SAME stream the kernel is launched on
+// (torch.cuda.Event would only see torch's current stream).  Off unless enabled.
+struct Timing {
+    struct Pair {
+        hipEvent_t start, stop;
+    };
+    static std::mutex& mu() {
+        static std::mutex m;
+        return m;
+    }
+    static bool& on() {
+        static bool v = false;
+        return v;
+    }
+    static std::vector<Pair>& pairs() {
+        static std::vector<Pair> v;
+        return v;
+    }
+    static hipEvent_t& pending() {
+        static thread_local hipEvent_t e = nullptr;
+        return e;
+    }
+    static int enable(bool v) {
+        std::lock_guard<std::mutex> lk(mu());
+        on() = v;
+        return NERF_HIP_OK;
+    }
+    static void before(hipStream_t st) {
+        pending() = nullptr;
+        if (!on()) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        hipEventRecord(e, st);
+        pending() = e;
+    }
+    static void after(hipStream_t st) {
+        if (pending() == nullptr) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            hipEventDestroy(pending());
+            pending() = nullptr;
+            return;
+        }
+        hipEventRecord(e, st);
+        std::lock_guard<std::mutex> lk(mu());
+        pairs().push_back(Pair{pending(), e});
+        pending() = nullptr;
+    }
+    static int read(bool reset, double* avg_ms, int64_t* launches) {
+        std::lock_guard<std::mutex> lk(mu());
+        double total = 0.0;
+        int64_t n = 0;
+        for (auto& p : pairs()) {
+            if (hipEventSynchronize(p.stop) != hipSuccess) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+                total += ms;
+                ++n;
+            }
+        }
+        if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
+        if (launches) *launches = n;
+        if (reset) {
+            for (auto& p : pairs()) {
+                hipEventDestroy(p.start);
+                hipEventDestroy(p.stop);
+            }
+            pairs().clear();
+        }
+        return NERF_HIP_OK;
+    }
+};
+
+}  // namespace nerf_common
+
+// Philox4x32-10 keyed by (seed), counter = (ray id lo, ray id hi, sample block + offset, stream).
+// Used only when the caller asks the kernel to draw u / noise itself (rng_mode); the parity path
+// takes the draws as inputs.
+namespace nerf_rng {
+
+__device__ __forceinline__ void round_(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__device__ __forceinline__ void philox(uint64_t seed, uint64_t offset, uint64_t ray, uint32_t block,
+                                       uint32_t stream, uint32_t (&c)[4]) {
+    c[0] = (uint32_t)ray;
+    c[1] = (uint32_t)(ray >> 32);
+    c[2] = block + (uint32_t)offset;
+    c[3] = stream ^ (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        round_(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// uniform in [0, 1) with 24 bits, like torch.rand for fp32
+__device__ __forceinline__ float uniform(uint64_t seed, uint64_t offset, uint64_t ray, uint32_t s,
+                                         uint32_t stream) {
+    uint32_t c[4];
+    philox(seed, offset, ray, s >> 2, stream, c);
+    const uint32_t x = c[s & 3];
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// standard normal by Box-Muller on two 24-bit uniforms of one Philox block
+__device__ __forceinline__ float normal(uint64_t seed, uint64_t offset, uint64_t ray, uint32_t s,
+                                        uint32_t stream) {
+    uint32_t c[4];
+    philox(seed, offset, ray, s >> 1, stream, c);
+    const uint32_t a = c[(s & 1) * 2], b = c[(s & 1) * 2 + 1];
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    return __builtin_sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+}  // namespace nerf_rng
+
+#endif

@@ -1,0 +1,58 @@
+// Shared constants: the packed parameter image streamed by the render kernels.
+//
+// MFMA used: v_mfma_f32_16x16x4_f32 (exact fp32, D = A[16x4] * B[4x16] + C).
+//   A operand: lane l holds A[row = l & 15][k = l >> 4]        -> weights
+//   B operand: lane l holds B[k = l >> 4][col = l & 15]        -> activations, col = sample
+//   C/D      : lane l, register reg holds D[row = 4 * (l >> 4) + reg][col = l & 15]
+// A wave owns 16 samples (the lane's `j = l & 15`) and ALL features of them: lane group
+// g = l >> 4 holds features f = 16 * t + 4 * g + r in register 4 * t + r.  With that map the
+// accumulator of one layer IS the B operand of the next (k index of MFMA step (t, r) on lane
+// group g = feature 16 t + 4 g + r), so activations never leave registers; only weights move.
+//
+// Weight image: 74 stages of 16 KiB.  A stage is 16 "quads" of 1 KiB; quad = the four A
+// operands (r = 0..3) of one (out-tile T, k-group t) pair, laid out [lane][r] so that one
+// ds_read_b128 per lane fetches them conflict-free and one global_load_lds_dwordx4 per wave
+// moves a whole quad.
+//   stages  0.. 5 : layer 0 (96 -> 256), stage = k-group t, quad = out-tile T (16 of them)
+//   stages  6..69 : layers 1..4 (256 -> 256), 16 stages each, same shape
+//   stages 70..73 : layer 5 (256 -> 64 padded), stage s holds k-groups 4s..4s+3,
+//                   quad = (t - 4 s) * 4 + T, T = 0..3
+// followed by the "small" image: per hidden layer L = 0..4 bias[256], gamma[256], beta[256],
+// each in [g][T][reg] order (feature 16 T + 4 g + reg), then the padded last bias [g][T(4)][reg].
+#ifndef NERF_LAYOUT_H
+#define NERF_LAYOUT_H
+
+namespace nerf_layout {
+
+constexpr int kHidden = 256;
+constexpr int kEncIn = 96;
+constexpr int kOut = 54;
+constexpr int kOutPad = 64;
+constexpr int kSegClasses = 50;
+
+constexpr int kStageBytes = 16384;
+constexpr int kStageFloats = kStageBytes / 4;
+constexpr int kQuadFloats = 256;
+constexpr int kStagesL0 = kEncIn / 16;            // 6
+constexpr int kStagesHidden = kHidden / 16;       // 16
+constexpr int kStagesL5 = 4;
+constexpr int kNumStages = kStagesL0 + 4 * kStagesHidden + kStagesL5;   // 74
+constexpr int kBlobFloats = kNumStages * kStageFloats;
+
+constexpr int kSmallPerLayer = 3 * kHidden;       // bias, gamma, beta
+constexpr int kSmallFloats = 5 * kSmallPerLayer + kOutPad;   // 3904
+constexpr int kPackedFloats = kBlobFloats + kSmallFloats;
+
+// Input-feature permutation of layer 0: lane group g computes, for the Gaussian of its sample,
+// the 12 (scale, coord) pairs with scale index 4 g .. 4 g + 3; local slot q = 4 t + r:
+//   q < 12 : sin part of pair q        q >= 12 : sin(. + pi/2) part of pair q - 12
+// Reference layout (nerf/model.py:158-163): [sin: scale-major x coord-minor | shifted: same].
+__host__ __device__ inline int layer0_source_feature(int t, int g, int r) {
+    const int q = 4 * t + r;
+    const int part = q / 12, p = q % 12;
+    const int scale = 4 * g + p / 3, coord = p % 3;
+    return part * 48 + 3 * scale + coord;
+}
+
+}  // namespace nerf_layout
+#endif

@@ -1,0 +1,388 @@
+"""Host-side mirror of ``nerf.model`` (generation C of brandontrabucco/nerf) for MI355X.
+
+Same importable names, constructor keywords, state-dict keys and method signatures as the
+reference's ``nerf/model.py`` so a caller switches with ``from nerf_amd.model import NeRF``.
+Everything ``NeRF.render_rays`` / ``render_image`` / ``forward`` compute is done by one fused HIP
+kernel behind the C ABI of ``include/nerf_hip.h``; torch only owns device memory and streams here.
+There is no CPU or eager fallback: tensors must live on a ROCm device and the library must be built.
+
+The small pose helpers (``generate_rays`` ... ``get_rotation_matrix``) and the module-level
+mip-NeRF functions stay thin torch expressions, as the reference has them, for debuggability;
+they are not on the hot path (``render_image`` generates its rays inside the kernel).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as functional
+
+from . import _lib
+
+__all__ = ["NeRF", "expected_sin", "lift_gaussian", "conical_frustum_to_gaussian", "cast_rays",
+           "integrated_pos_enc"]
+
+_LOG2_NEAR = -9.43633744014          # nerf/model.py:414
+
+
+# ----------------------------------------------------------------------------------------------
+# module-level helpers (reference: nerf/model.py:24-163) — debugging aids, plain torch
+# ----------------------------------------------------------------------------------------------
+
+def expected_sin(x, x_var):
+    """Mean and variance of sin(z), z ~ N(x, x_var)  (nerf/model.py:24-30)."""
+    damp = torch.exp(-0.5 * x_var)
+    y = damp * torch.sin(x)
+    y_var = (0.5 * (1 - torch.exp(-2 * x_var) * torch.cos(2 * x)) - y ** 2).clamp(min=0.0)
+    return y, y_var
+
+
+def lift_gaussian(d, t_mean, t_var, r_var, diag=True):
+    """Gaussian along a ray -> 3-D diagonal Gaussian  (nerf/model.py:33-45; diag only)."""
+    if not diag:
+        raise NotImplementedError("full covariance is unreachable from NeRF (nerf/model.py:46-53)")
+    mean = d[..., None, :] * t_mean[..., None]
+    d_sq = d ** 2
+    mag = torch.sum(d_sq, dim=-1, keepdim=True).clamp(min=1e-10)
+    cov = t_var[..., None] * d_sq[..., None, :] + r_var[..., None] * (1 - d_sq / mag)[..., None, :]
+    return mean, cov
+
+
+def conical_frustum_to_gaussian(d, t0, t1, base_radius, diag=True, stable=True):
+    """Conical frustum [t0, t1] -> Gaussian, stable form  (nerf/model.py:56-87)."""
+    if not stable:
+        raise NotImplementedError("only the stable formulation is on the render path")
+    mu, hw = (t0 + t1) / 2, (t1 - t0) / 2
+    denom = 3 * mu ** 2 + hw ** 2
+    t_mean = mu + (2 * mu * hw ** 2) / denom
+    t_var = (hw ** 2) / 3 - (4 / 15) * ((hw ** 4 * (12 * mu ** 2 - hw ** 2)) / denom ** 2)
+    r_var = base_radius ** 2 * ((mu ** 2) / 4 + (5 / 12) * hw ** 2 - 4 / 15 * (hw ** 4) / denom)
+    return lift_gaussian(d, t_mean, t_var, r_var, diag)
+
+
+def cast_rays(t_vals, origins, directions, radii, ray_shape="cone", diag=True):
+    """Fenceposts -> per-interval Gaussians  (nerf/model.py:112-136; cone only)."""
+    if ray_shape != "cone":
+        raise NotImplementedError("NeRF only casts cones (nerf/model.py:548)")
+    means, covs = conical_frustum_to_gaussian(directions, t_vals[..., :-1], t_vals[..., 1:],
+                                              radii, diag)
+    return means + origins[..., None, :], covs
+
+
+def integrated_pos_enc(x_coord, min_deg, max_deg):
+    """Integrated positional encoding of (mean, diag cov)  (nerf/model.py:139-163)."""
+    x, x_cov = x_coord
+    scales = torch.as_tensor([2 ** i for i in range(min_deg, max_deg)]).to(x)
+    shape = list(x.shape[:-1]) + [-1]
+    y = (x[..., None, :] * scales[:, None]).reshape(*shape)
+    y_var = (x_cov[..., None, :] * scales[:, None] ** 2).reshape(*shape)
+    return expected_sin(torch.cat([y, y + 0.5 * np.pi], dim=-1), torch.cat([y_var] * 2, dim=-1))[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# the renderer
+# ----------------------------------------------------------------------------------------------
+
+def _require_device(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"nerf_amd: `{name}` is on {t.device}; the renderer runs on an MI355X "
+                           "(ROCm device) only and has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"nerf_amd: `{name}` must be float32, got {t.dtype}")
+
+
+class NeRF(nn.Module):
+    """mip-NeRF-style radiance field with the call surface of the reference's ``NeRF``
+    (nerf/model.py:166-770): LayerNorm MLP 96-256x5-54 on integrated positional encodings of
+    conical frusta, one output head split into density | color | segmentation."""
+
+    def __init__(self, color_outputs=3, segmentation_outputs=50, hidden_size=256, encoding_size=32,
+                 focal_length=112.0, min_x=-20.0, max_x=20.0, min_y=-20.0, max_y=20.0,
+                 min_z=-20.0, max_z=20.0):
+        super().__init__()
+        self.focal_length = focal_length
+        self.color_outputs = color_outputs
+        self.segmentation_outputs = segmentation_outputs
+        self.hidden_size = hidden_size
+        self.encoding_size = encoding_size
+        self.register_buffer("rays_min", torch.as_tensor([[[min_x, min_y, min_z]]],
+                                                         dtype=torch.float32))
+        self.register_buffer("rays_max", torch.as_tensor([[[max_x, max_y, max_z]]],
+                                                         dtype=torch.float32))
+        # Parameter container with the reference's module tree (nerf/model.py:525-542) so that
+        # state-dict keys, default initialisation and RNG consumption are identical.  The
+        # modules are never called: the fused kernel reads their tensors.
+        layers = [nn.Linear(3 * encoding_size, hidden_size), nn.LayerNorm(hidden_size), nn.ReLU()]
+        for _ in range(4):
+            layers += [nn.Linear(hidden_size, hidden_size), nn.LayerNorm(hidden_size), nn.ReLU()]
+        layers.append(nn.Linear(hidden_size, 1 + color_outputs + segmentation_outputs))
+        self.prediction_heads = nn.Sequential(*layers)
+        # rng: "torch" draws u / noise with torch's generator exactly where the reference does
+        # (model.py:432, :652); "philox" lets the kernel draw them (no HBM round trip).
+        self.rng = "torch"
+        self._packed = None
+        self._packed_key = None
+        self._tables = {}
+        self._philox_calls = 0
+
+    # ---- statics (reference: nerf/model.py:243-367, :438-469) --------------------------------
+
+    @staticmethod
+    def generate_rays(image_h, image_w, focal_length, dtype=torch.float32, device="cpu"):
+        """Camera-frame pinhole ray per pixel, [H, W, 3] = (x, -y, -1)  (nerf/model.py:243-278)."""
+        rows = torch.arange(image_h, dtype=dtype, device=device)
+        cols = torch.arange(image_w, dtype=dtype, device=device)
+        yy, xx = torch.meshgrid(rows, cols, indexing="ij")
+        xx = (xx - 0.5 * float(image_w - 1)) / focal_length
+        yy = (yy - 0.5 * float(image_h - 1)) / focal_length
+        return torch.stack([xx, -yy, -torch.ones_like(xx)], dim=-1)
+
+    @staticmethod
+    def spherical_to_cartesian(yaw, elevation):
+        """Unit vector of (yaw, elevation), z up  (nerf/model.py:281-306)."""
+        ce = torch.cos(elevation)
+        return torch.stack([torch.cos(yaw) * ce, torch.sin(yaw) * ce, torch.sin(elevation)], dim=-1)
+
+    @staticmethod
+    def get_rotation_matrix(eye_vector, up_vector):
+        """Camera-to-world rotation with columns [eye x up, up, -eye]  (nerf/model.py:309-334).
+        The reference calls ``torch.cross`` without ``dim``, which crosses along the FIRST axis of
+        size 3 (so a batch of exactly three poses is crossed along the batch axis); kept."""
+        dim = next(i for i, n in enumerate(eye_vector.shape) if n == 3)
+        side = torch.linalg.cross(eye_vector, up_vector, dim=dim)
+        return torch.stack([side, up_vector, -eye_vector], dim=-1)
+
+    @staticmethod
+    def rays_to_world_coordinates(rays, camera_o, camera_r):
+        """(origin, R . ray)  (nerf/model.py:337-367)."""
+        return camera_o, (camera_r * rays.unsqueeze(-2)).sum(dim=-1)
+
+    @staticmethod
+    def alpha_compositing_coefficients(points, density_outputs):
+        """Compositing weights from points [.., P, 3] and densities [.., P, 1]
+        (nerf/model.py:438-469); torch helper, the renderer computes these in-kernel."""
+        gaps = points[..., 1:, :] - points[..., :-1, :]
+        dists = functional.pad(torch.linalg.norm(gaps, dim=-1, keepdim=True), (0, 0, 0, 1),
+                               value=1e10)
+        trans = torch.exp(-functional.relu(density_outputs) * dists)
+        return (1.0 - trans) * functional.pad(
+            torch.cumprod(trans[..., :-1, :] + 1e-10, dim=-2), (0, 0, 1, 0), value=1.0)
+
+    # ---- sampling ------------------------------------------------------------------------------
+
+    def _fencepost_table(self, num_samples, device):
+        """Unscaled 2^linspace table (nerf/model.py:414-415), built with the same torch CPU ops as
+        the reference and cached on the device."""
+        key = (int(num_samples), str(device))
+        if key not in self._tables:
+            table = torch.pow(2.0, torch.linspace(_LOG2_NEAR, 0.0, num_samples,
+                                                  dtype=torch.float32))
+            self._tables[key] = table.to(device)
+        return self._tables[key]
+
+    def _t_scale(self):
+        return float(torch.linalg.norm(self.rays_max.detach().cpu() - self.rays_min.detach().cpu()))
+
+    def sample_along_rays(self, rays_o, rays_d, num_samples, states_x=None, states_d=None,
+                          randomly_sample=True):
+        """Fenceposts [..., S] along each ray, log-spaced, optionally stratified
+        (nerf/model.py:369-435).  Only the shape/device of ``rays_o`` matters."""
+        lead = list(rays_o.shape[:-1])
+        table = self._fencepost_table(num_samples, rays_o.device).to(rays_o.dtype)
+        samples = torch.broadcast_to(table.reshape([1] * len(lead) + [num_samples]),
+                                     lead + [num_samples])
+        if randomly_sample:
+            mid = 0.5 * (samples[..., 1:] + samples[..., :-1])
+            lower = torch.cat([samples[..., :1], mid], dim=-1)
+            upper = torch.cat([mid, samples[..., -1:]], dim=-1)
+            draw = torch.rand(*samples.shape, dtype=rays_o.dtype, device=rays_o.device)
+            samples = lower + (upper - lower) * draw
+        return samples * torch.linalg.norm(self.rays_max - self.rays_min)
+
+    # ---- plumbing to the C ABI -------------------------------------------------------------------
+
+    def _check_shape(self):
+        if (self.hidden_size, self.encoding_size,
+                1 + self.color_outputs + self.segmentation_outputs, self.color_outputs) != (256, 32, 54, 3):
+            raise NotImplementedError(
+                "libnerf_hip is compiled for the reference's default network "
+                "(hidden_size=256, encoding_size=32, 3 color + 50 segmentation outputs)")
+
+    def _param_list(self):
+        heads = self.prediction_heads
+        order = []
+        for slot in (0, 1, 3, 4, 6, 7, 9, 10, 12, 13, 15):
+            order += [heads[slot].weight, heads[slot].bias]
+        return order
+
+    def packed_parameters(self):
+        """The parameters re-laid for the kernels (nerf_hip_pack_weights); re-packed whenever a
+        parameter tensor was modified in place or replaced."""
+        self._check_shape()
+        params = self._param_list()
+        dev = params[0].device
+        for p in params:
+            _require_device(p, "parameter")
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed_key != key or self._packed.device != dev:
+            lib = _lib.lib()
+            keep = [p.detach().contiguous() for p in params]
+            ptrs = (ctypes.c_void_p * _lib.NUM_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
+            packed = torch.empty(lib.nerf_hip_packed_bytes() // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(lib.nerf_hip_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
+                           "nerf_hip_pack_weights")
+            self._packed, self._packed_key = packed, key
+        return self._packed
+
+    def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
+                ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
+                want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None):
+        lib = _lib.lib()
+        packed = self.packed_parameters()
+        P = num_samples - 1
+        if rgb is None:
+            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
+        if seg is None and want_seg:
+            seg = torch.empty(n_rays, self.segmentation_outputs, dtype=torch.float32, device=device)
+        mean = raw = weights = None
+        if per_sample:
+            mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
+            raw = torch.empty(n_rays, P, 54, dtype=torch.float32, device=device)
+            weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
+        args = _lib.RenderArgs()
+        args.rays_o, args.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
+        if cameras is not None:
+            cam_o, cam_r, image_h, image_w, focal = cameras
+            args.camera_o, args.camera_r = _lib.ptr(cam_o), _lib.ptr(cam_r)
+            args.image_h, args.image_w, args.focal_length = image_h, image_w, float(focal)
+        args.ray_begin, args.n_rays, args.num_samples = int(ray_begin), int(n_rays), int(num_samples)
+        table = self._fencepost_table(num_samples, device)
+        args.t_table, args.t_scale = _lib.ptr(table), self._t_scale()
+        args.t_values, args.u, args.noise = _lib.ptr(t_values), _lib.ptr(u), _lib.ptr(noise)
+        args.density_noise_std = float(density_noise_std)
+        args.rng_mode = int(rng_mode)
+        if rng_mode:
+            if rng_state is None:
+                rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_calls)
+                self._philox_calls += 1
+            args.rng_seed, args.rng_offset = rng_state
+        r_dot = 1.0 / (math.sqrt(3.0) * self.focal_length)          # nerf/model.py:546
+        args.base_radius_sq = r_dot ** 2
+        args.packed = _lib.ptr(packed)
+        args.rgb, args.seg = _lib.ptr(rgb), _lib.ptr(seg)
+        args.out_mean, args.out_raw, args.out_weights = _lib.ptr(mean), _lib.ptr(raw), _lib.ptr(weights)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nerf_hip_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_render_forward")
+        return rgb, seg, mean, raw, weights
+
+    def _draws(self, n_rays, num_samples, device, randomly_sample, density_noise_std):
+        """u / noise for a batch.  "torch": consume torch's generator exactly like the reference
+        (rand only when stratified, randn always — model.py:432, :652).  "philox": in-kernel."""
+        if self.rng == "philox":
+            mode = (1 if randomly_sample else 0) | (2 if density_noise_std != 0.0 else 0)
+            return None, None, mode
+        u = torch.rand(n_rays, num_samples, dtype=torch.float32, device=device) \
+            if randomly_sample else None
+        noise = torch.randn(n_rays, num_samples - 1, 1, dtype=torch.float32, device=device)
+        if density_noise_std == 0.0:
+            noise = None                       # drawn (generator advanced) but adds nothing
+        return u, noise, 0
+
+    # ---- the reference's methods -----------------------------------------------------------------
+
+    def forward(self, rays_o, rays_d, samples, states_x=None, states_d=None):
+        """Field values on the intervals of ``samples`` [N, S]: returns (mean [N,S-1,3],
+        density [N,S-1,1], color [N,S-1,3], segmentation [N,S-1,50])  (nerf/model.py:553-594).
+        ``states_*`` are accepted and ignored, as in the reference."""
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        _require_device(samples, "samples")
+        n_rays, num_samples = samples.shape[0], samples.shape[-1]
+        _, _, mean, raw, _ = self._launch(
+            n_rays, num_samples, rays_o.device, rays_o=rays_o.detach().contiguous(),
+            rays_d=rays_d.detach().contiguous(), t_values=samples.detach().contiguous(),
+            want_seg=False, per_sample=True)
+        density, color, seg = raw.split([1, self.color_outputs, self.segmentation_outputs], dim=2)
+        return mean, density, color, seg
+
+    def render_rays(self, rays_o, rays_d, num_samples, states_x=None, states_d=None,
+                    randomly_sample=False, density_noise_std=0.0, u=None, noise=None):
+        """Render a batch of rays: returns (image [N,1,3], segmentation [N,1,50]); the middle axis
+        is the reference's (single) stage axis  (nerf/model.py:596-668).
+
+        Extension: ``u`` [N,S] and ``noise`` [N,S-1,1] may be passed to replace the random draws
+        (bit-reproducible stochastic path); otherwise they are drawn per ``self.rng``."""
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        lead = rays_o.shape[:-1]
+        flat_o = rays_o.detach().reshape(-1, 3).contiguous()
+        flat_d = rays_d.detach().reshape(-1, 3).contiguous()
+        n_rays = flat_o.shape[0]
+        mode = 0
+        if u is None and noise is None:
+            u, noise, mode = self._draws(n_rays, num_samples, flat_o.device, randomly_sample,
+                                         density_noise_std)
+        u = None if u is None else u.detach().reshape(n_rays, num_samples).contiguous()
+        noise = None if noise is None else noise.detach().reshape(n_rays, num_samples - 1).contiguous()
+        from .autograd import render_rays_function            # local: autograd layer is optional
+        rgb, seg = render_rays_function(self, flat_o, flat_d, num_samples, u, noise,
+                                        float(density_noise_std), mode)
+        return (rgb.reshape(*lead, 1, self.color_outputs),
+                seg.reshape(*lead, 1, self.segmentation_outputs))
+
+    def render_image(self, camera_o, camera_r, image_h, image_w, focal_length, num_samples,
+                     states_x=None, states_d=None, max_chunk_size=1024, randomly_sample=False,
+                     density_noise_std=0.0, row_begin=0, row_end=None):
+        """Render full frames: returns (image [B,H,W,3], segmentation [B,H,W,50])
+        (nerf/model.py:670-770).  Rays are generated inside the kernel from the poses; the frame
+        is one launch, so ``max_chunk_size`` (the reference's memory knob) only bounds the size
+        of the random-draw tensors on the stochastic path.
+
+        Extension for multi-GPU sharding: ``row_begin``/``row_end`` render only that block of
+        image rows (of every frame in the batch) and return [B, rows, W, .]."""
+        _require_device(camera_o, "camera_o"), _require_device(camera_r, "camera_r")
+        device = camera_o.device
+        batch = camera_o.shape[0]
+        row_end = image_h if row_end is None else row_end
+        rows = row_end - row_begin
+        cam_o = camera_o.detach().contiguous()
+        cam_r = camera_r.detach().contiguous()
+        cameras = (cam_o, cam_r, image_h, image_w, focal_length)
+        stochastic = randomly_sample or density_noise_std != 0.0
+        rgb_out = torch.empty(batch, rows, image_w, self.color_outputs, dtype=torch.float32,
+                              device=device)
+        seg_out = torch.empty(batch, rows, image_w, self.segmentation_outputs, dtype=torch.float32,
+                              device=device)
+        for b in range(batch):
+            begin = (b * image_h + row_begin) * image_w
+            n_rays = rows * image_w
+            if not stochastic or self.rng == "philox":
+                # one launch per frame, written straight into the output block.  (On the
+                # deterministic path the reference still draws a randn per chunk that it then
+                # multiplies by 0, model.py:652-654; that dead draw is not reproduced here.)
+                mode = 0
+                if stochastic:
+                    mode = (1 if randomly_sample else 0) | (2 if density_noise_std != 0.0 else 0)
+                self._launch(n_rays, num_samples, device, cameras=cameras, ray_begin=begin,
+                             density_noise_std=density_noise_std, rng_mode=mode,
+                             rgb=rgb_out[b].reshape(n_rays, -1), seg=seg_out[b].reshape(n_rays, -1))
+                continue
+            # stochastic with torch draws: chunk so the draw tensors stay small, same draw order
+            # per chunk as the reference's loop (model.py:757-761)
+            flat_rgb = rgb_out[b].reshape(n_rays, -1)
+            flat_seg = seg_out[b].reshape(n_rays, -1)
+            step = max(int(max_chunk_size), 1)
+            for lo in range(0, n_rays, step):
+                n = min(step, n_rays - lo)
+                u, noise, mode = self._draws(n, num_samples, device, randomly_sample, density_noise_std)
+                u = None if u is None else u.contiguous()
+                noise = None if noise is None else noise.reshape(n, num_samples - 1).contiguous()
+                rgb, seg, _, _, _ = self._launch(n, num_samples, device, cameras=cameras,
+                                                 ray_begin=begin + lo, u=u, noise=noise,
+                                                 density_noise_std=density_noise_std, rng_mode=mode)
+                flat_rgb[lo:lo + n] = rgb
+                flat_seg[lo:lo + n] = seg
+        return rgb_out, seg_out
