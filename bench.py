@@ -1,0 +1,194 @@
+"""Headline benchmark: ray-samples/sec of the fused MI355X renderer on a synthetic
+800x800 frame at 128 samples per ray (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = NeRF.render_image of one full frame per GPU (rays generated in-kernel from the pose,
+deterministic fenceposts, RGB + 50-class segmentation composited): the whole hot path, inputs
+(pose, packed parameters) resident in HBM.  Frames are independent, so ranks shard a batch of
+N poses one frame each with no data-path collective ("weak" scaling; ``--scaling strong`` splits
+ONE frame into row blocks instead).  Rank 0 prints one JSON line.
+
+roofline: the render kernel is MFMA-bound (exact-fp32 v_mfma_f32_16x16x4_f32); achieved =
+evaluated samples per launch x 601,088 FLOP / average kernel duration measured with HIP events
+on the launch stream; peak = 157.3 TFLOP/s (fp32 matrix peak, MI355X_MICROARCH.md).
+cpu_baseline: the oracle (a torch-CPU port of the reference, oracle/nerf_oracle.py) timed on
+this box's host cores on a bounded block of rows of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+IMAGE = 800
+SAMPLES = 128
+FOCAL = 896.0
+FLOP_PER_SAMPLE = 601088          # 2*(96*256 + 4*256*256 + 256*54), SURVEY.md section 8d
+PEAK_TFLOPS_FP32_MFMA = 157.3     # MI355X_MICROARCH.md, chip-level parameters
+CAMERA = (0.0, -3.0, 2.6)
+
+
+def look_at(camera_o):
+    """Pose looking at the origin, z up, built like the reference's get_rotation_matrix."""
+    from nerf_amd import NeRF
+    cam = torch.tensor([camera_o], dtype=torch.float32)
+    eye = -cam / torch.linalg.norm(cam, dim=-1, keepdim=True)
+    z = torch.tensor([[0.0, 0.0, 1.0]])
+    up = z - (z * eye).sum(-1, keepdim=True) * eye
+    up = up / torch.linalg.norm(up, dim=-1, keepdim=True)
+    return cam, NeRF.get_rotation_matrix(eye, up)
+
+
+def cpu_baseline(rows=32):
+    """Oracle render of `rows` image rows of the bench frame on the host cores."""
+    from oracle import nerf_oracle as O
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    params = O.init_params(seed=0)
+    cfg = dict(O.default_config(), focal_length=FOCAL)
+    cam_o, cam_r = look_at(CAMERA)
+    rays_o, rays_d = O.image_rays(cam_o, cam_r, IMAGE, IMAGE, FOCAL)
+    r0 = (IMAGE - rows) // 2
+    sl = slice(r0 * IMAGE, (r0 + rows) * IMAGE)
+    o, d = rays_o[sl], rays_d[sl]
+    with torch.no_grad():
+        O.render_rays(params, cfg, o[:1024], d[:1024], SAMPLES)          # warm-up
+        t0 = time.perf_counter()
+        for a, b in zip(torch.split(o, 1024), torch.split(d, 1024)):
+            O.render_rays(params, cfg, a, b, SAMPLES)
+        dt = time.perf_counter() - t0
+    return {"value": rows * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{rows} rows x {IMAGE} px of the same 800x800x128 frame, chunks of 1024 rays, "
+                      f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+
+    from nerf_amd import NeRF, _lib
+    torch.manual_seed(0)
+    model = NeRF(focal_length=FOCAL).to(dev)         # default init, seed 0, on every rank
+
+    # a batch of `world` poses on a circle of the same radius; rank r renders frame r (weak) or
+    # its row block of frame 0 (strong)
+    import math
+    if args.scaling == "weak":
+        ang = 2.0 * math.pi * rank / max(world, 1)
+        r_xy = math.hypot(CAMERA[0], CAMERA[1])
+        pose = (r_xy * math.sin(ang), -r_xy * math.cos(ang), CAMERA[2])
+        rows = (0, IMAGE)
+    else:
+        pose = CAMERA
+        per = IMAGE // world
+        rows = (rank * per, IMAGE if rank == world - 1 else (rank + 1) * per)
+    cam_o, cam_r = look_at(pose)
+    cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES,
+                                      row_begin=rows[0], row_end=rows[1])
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.timing(True)
+    _lib.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = _lib.timing_read(reset=True)
+    _lib.timing(False)
+    assert torch.isfinite(out[0]).all()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    rays_per_rank = (rows[1] - rows[0]) * IMAGE
+    total_rays = rays_per_rank * world if args.scaling == "weak" else IMAGE * IMAGE
+    value = total_rays * SAMPLES * args.steps / elapsed
+
+    if rank == 0:
+        evaluated = rays_per_rank * (SAMPLES - 1)
+        achieved = evaluated * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
+        line = {
+            "metric": "ray-samples/sec at 800x800x128",
+            "value": value,
+            "unit": "ray-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "NeRF.render_image 800x800, 128 samples/ray (127 evaluated), RGB + 50-class "
+                            "segmentation, rays generated in-kernel, default-init weights seed 0",
+                "rays_per_gpu": rays_per_rank,
+                "frames": world if args.scaling == "weak" else 1,
+                "sharding": "one frame per GPU" if args.scaling == "weak" else "row blocks of one frame",
+                "collectives": "none",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_TFLOPS_FP32_MFMA,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_TFLOPS_FP32_MFMA if achieved else None,
+                "traffic": None,
+                "kernel": "nerf_render_fwd_kernel",
+                "kernel_ms": kernel_ms,
+                "launches_timed": launches,
+                "flop_per_launch": evaluated * FLOP_PER_SAMPLE,
+                "peak_note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peak; algorithmic FLOPs only",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
