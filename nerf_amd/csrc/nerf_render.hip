@@ -486,13 +486,16 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             }
         }
 
-        // ---- ray epilogue ----
-        if (ray_ok && lane == 0) {
-            a.rgb[local * 3 + 0] = rgb0;
-            a.rgb[local * 3 + 1] = rgb1;
-            a.rgb[local * 3 + 2] = rgb2;
+        // ---- ray epilogue: one coalesced store instruction per output row ----
+        if (ray_ok && lane < 3) {
+            const float v = lane == 0 ? rgb0 : (lane == 1 ? rgb1 : rgb2);
+            a.rgb[local * 3 + lane] = v;
         }
         if (a.seg != nullptr) {
+            // after the row reductions every lane of a row holds the same 16 values; lane (j, g)
+            // keeps slot i = j, i.e. output n = 16 (j >> 2) + 4 g + (j & 3), so the wave's 64 lanes
+            // cover n = 0..63 once and the 50 class values leave in one store instruction.
+            float mine = 0.f;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -500,10 +503,11 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                     const int i = 4 * T + r;
                     const float mx = row_max(segM[i]);
                     const float sm = row_sum(segS[i] * expf(segM[i] - mx));
-                    const int n = 16 * T + 4 * g + r;
-                    if (ray_ok && j == 0 && n >= 4 && n < kOut)
-                        a.seg[local * kSegClasses + (n - 4)] = mx + logf(sm);
+                    const float val = mx + logf(sm);
+                    if (j == i) mine = val;
                 }
+            const int n = 16 * (j >> 2) + 4 * g + (j & 3);
+            if (ray_ok && n >= 4 && n < kOut) a.seg[local * kSegClasses + (n - 4)] = mine;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

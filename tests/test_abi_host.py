@@ -1,0 +1,131 @@
+"""CPU tests of the boundary: the C-ABI library builds/loads without a GPU and exports every
+symbol include/nerf_hip.h declares; the Python mirror keeps the reference's call surface."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_hip_[a-z_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def handle():
+    from nerf_amd import build as nerf_build
+    nerf_build.build()
+    from nerf_amd import _lib
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(handle):
+    from nerf_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 7
+    for name in names:
+        assert hasattr(handle, name), name
+    assert set(_lib.EXPORTS) == set(names)
+    assert handle.nerf_hip_version() == 1
+    # packed image = 74 stages x 16 KiB + 3,904 small floats
+    assert handle.nerf_hip_packed_bytes() == 74 * 16384 + 3904 * 4
+
+
+def test_args_struct_matches_header():
+    """Field order/names of the ctypes mirror == the C struct (guards silent ABI drift)."""
+    from nerf_amd import _lib
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    body = text[text.index("typedef struct NerfHipRenderArgs"):text.index("} NerfHipRenderArgs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].split()[-1].lstrip("*")
+        fields.append(first)
+        fields += [n.strip().lstrip("*") for n in names[1:]]
+    assert fields == [f[0] for f in _lib.RenderArgs._fields_]
+
+
+def test_argument_errors_do_not_touch_the_gpu(handle):
+    from nerf_amd import _lib
+    assert handle.nerf_hip_render_forward(None, None) == -1
+    assert b"null args" in handle.nerf_hip_last_error()
+    args = _lib.RenderArgs()
+    args.n_rays, args.num_samples = 8, 1
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
+    args.n_rays = 0                       # empty batch is a no-op, not an error
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == 0
+    assert handle.nerf_hip_pack_weights(None, None, None) == -1
+
+
+def test_mirror_keeps_reference_call_surface():
+    from nerf_amd.model import NeRF
+    import nerf_amd.model as m
+    for fn in ("expected_sin", "lift_gaussian", "conical_frustum_to_gaussian", "cast_rays",
+               "integrated_pos_enc"):
+        assert callable(getattr(m, fn))
+    sig = inspect.signature(NeRF.__init__)
+    assert list(sig.parameters)[1:] == ["color_outputs", "segmentation_outputs", "hidden_size",
+                                        "encoding_size", "focal_length", "min_x", "max_x", "min_y",
+                                        "max_y", "min_z", "max_z"]
+    assert list(inspect.signature(NeRF.render_rays).parameters)[:8] == [
+        "self", "rays_o", "rays_d", "num_samples", "states_x", "states_d", "randomly_sample",
+        "density_noise_std"]
+    assert list(inspect.signature(NeRF.render_image).parameters)[:12] == [
+        "self", "camera_o", "camera_r", "image_h", "image_w", "focal_length", "num_samples",
+        "states_x", "states_d", "max_chunk_size", "randomly_sample", "density_noise_std"]
+    assert list(inspect.signature(NeRF.forward).parameters) == [
+        "self", "rays_o", "rays_d", "samples", "states_x", "states_d"]
+    torch.manual_seed(0)
+    model = NeRF()
+    from conftest import golden_params
+    ref = golden_params()
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:                         # same init under the same seed as the reference
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_host_helpers_match_reference_fixtures():
+    from conftest import load_golden
+    from nerf_amd.model import NeRF
+    g = load_golden("g7_statics")
+    assert torch.equal(NeRF.generate_rays(5, 7, 112.0), g["rays_5x7"])
+    assert torch.equal(NeRF.spherical_to_cartesian(g["yaw"], g["elevation"]), g["cartesian"])
+    rot = NeRF.get_rotation_matrix(g["cartesian"], g["up"])
+    assert torch.equal(rot, g["rotation"])
+    _, wd = NeRF.rays_to_world_coordinates(g["rays_5x7"][None], g["cartesian"][:, None, None, :] * 2.0,
+                                           rot[:, None, None, :, :])
+    assert torch.equal(wd, g["world_d"])
+    model = NeRF()
+    t = model.sample_along_rays(torch.zeros(2, 3), torch.zeros(2, 3), 64, randomly_sample=False)
+    assert torch.equal(t[1], g["t64"])
+    g1 = load_golden("g1_stages")
+    w = NeRF.alpha_compositing_coefficients(g1["means"], g1["density"])
+    assert torch.equal(w, g1["weights"])
+
+
+def test_no_cpu_fallback():
+    from nerf_amd.model import NeRF
+    model = NeRF()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model.render_rays(torch.zeros(4, 3), torch.ones(4, 3), 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model.render_image(torch.zeros(1, 3), torch.eye(3)[None], 4, 4, 4.0, 8)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nerf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", ""), f
