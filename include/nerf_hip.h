@@ -95,11 +95,36 @@ typedef struct NerfHipRenderArgs {
     float* out_mean;            /* [n_rays,S-1,3]                                          */
     float* out_raw;             /* [n_rays,S-1,54] density | color | segmentation logits   */
     float* out_weights;         /* [n_rays,S-1] compositing weights (model.py:438-469)     */
+    /* training: non-NULL makes the forward also save what the backward needs (activations,
+     * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats      */
+    float* train_workspace;
 } NerfHipRenderArgs;
 
 /* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional
  * encoding -> 6-layer MLP on fp32 MFMA -> alpha compositing.  One persistent launch. */
 int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream);
+
+/* Bytes of `train_workspace` for a batch of n_rays rays at num_samples fenceposts. */
+size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples);
+
+/* Number of fp32 elements of the flat gradient vector (304,438): the 22 parameter tensors in
+ * state_dict order, each in its PyTorch layout. */
+size_t nerf_hip_grad_elements(void);
+
+/* Backward of nerf_hip_render_forward w.r.t. the parameters (replaces PyTorch autograd through
+ * NeRF.render_rays, driven by loss.backward() at train_conditional_nerf.py:133).  `fwd` must be
+ * the argument block of the training forward call (same rays, sampling inputs, draws, packed
+ * image and train_workspace, which that call filled); rays are not differentiated. */
+typedef struct NerfHipBackwardArgs {
+    NerfHipRenderArgs fwd;
+    const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
+    const float* d_seg;         /* [n_rays,50] dL/d seg or NULL (RGB-only loss)           */
+    float* grad;                /* [nerf_hip_grad_elements()] written (not accumulated)    */
+    float* scratch;             /* nerf_hip_backward_scratch_bytes() bytes                 */
+} NerfHipBackwardArgs;
+
+size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples);
+int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream);
 
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing

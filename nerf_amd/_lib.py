@@ -31,7 +31,14 @@ class RenderArgs(ctypes.Structure):
         ("packed", _f32p),
         ("rgb", _f32p), ("seg", _f32p),
         ("out_mean", _f32p), ("out_raw", _f32p), ("out_weights", _f32p),
+        ("train_workspace", _f32p),
     ]
+
+
+class BackwardArgs(ctypes.Structure):
+    """Mirror of NerfHipBackwardArgs (include/nerf_hip.h)."""
+    _fields_ = [("fwd", RenderArgs), ("d_rgb", _f32p), ("d_seg", _f32p), ("grad", _f32p),
+                ("scratch", _f32p)]
 
 
 _lib = None
@@ -55,6 +62,13 @@ def lib():
                                              ctypes.c_void_p]
     handle.nerf_hip_render_forward.restype = ctypes.c_int
     handle.nerf_hip_render_forward.argtypes = [ctypes.POINTER(RenderArgs), ctypes.c_void_p]
+    handle.nerf_hip_train_workspace_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_train_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    handle.nerf_hip_grad_elements.restype = ctypes.c_size_t
+    handle.nerf_hip_backward_scratch_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_backward_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    handle.nerf_hip_render_backward.restype = ctypes.c_int
+    handle.nerf_hip_render_backward.argtypes = [ctypes.POINTER(BackwardArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -67,8 +81,9 @@ def lib():
 
 
 EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_packed_bytes",
-           "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_timing",
-           "nerf_hip_timing_read")
+           "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
+           "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
+           "nerf_hip_timing", "nerf_hip_timing_read")
 
 
 def check(rc, what):

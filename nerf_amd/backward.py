@@ -1,0 +1,76 @@
+"""torch.autograd bridge for the HIP backward (include/nerf_hip.h: nerf_hip_render_backward).
+
+Forward = the fused render kernel in training mode (it also saves activations, LayerNorm
+statistics and compositing state to a workspace); backward = three HIP launches that produce
+the flat parameter-gradient vector (304,438 fp32, state_dict order).  Rays, fenceposts and
+random draws receive no gradient (the reference never asks for one).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class RenderRaysFunction(torch.autograd.Function):
+    """rgb [N,3], seg [N,50] = f(parameters); inputs after `rng_mode` are the 22 parameters."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode,
+                *params):
+        lib = _lib.lib()
+        n_rays, device = rays_o.shape[0], rays_o.device
+        ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
+        workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
+        rng_state = None
+        if rng_mode:
+            rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, model._philox_calls)
+            model._philox_calls += 1
+        rgb, seg, _, _, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
+                                          u=u, noise=noise, density_noise_std=density_noise_std,
+                                          rng_mode=rng_mode, rng_state=rng_state,
+                                          train_workspace=workspace)
+        ctx.model = model
+        ctx.call = (rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode, rng_state)
+        ctx.workspace = workspace
+        ctx.packed = model.packed_parameters()      # the image this forward used
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(rgb, seg)
+        ctx.mark_non_differentiable()
+        return rgb, seg
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_seg):
+        lib = _lib.lib()
+        model = ctx.model
+        rgb, seg = ctx.saved_tensors
+        rays_o, rays_d, num_samples, u, noise, std, rng_mode, rng_state = ctx.call
+        n_rays, device = rays_o.shape[0], rays_o.device
+        if d_rgb is None:
+            d_rgb = torch.zeros_like(rgb)
+        d_rgb = d_rgb.contiguous()
+        use_seg = d_seg is not None and bool((d_seg != 0).any())
+        d_seg = d_seg.contiguous() if use_seg else None
+
+        args = _lib.BackwardArgs()
+        model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, u=u,
+                         noise=noise, density_noise_std=std, rng_mode=rng_mode, rng_state=rng_state,
+                         packed=ctx.packed, rgb=rgb, seg=seg, train_workspace=ctx.workspace)
+        grad = torch.empty(lib.nerf_hip_grad_elements(), dtype=torch.float32, device=device)
+        scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
+        args.d_rgb, args.d_seg = _lib.ptr(d_rgb), _lib.ptr(d_seg)
+        args.grad, args.scratch = _lib.ptr(grad), _lib.ptr(scratch)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nerf_hip_render_backward(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_render_backward")
+        ctx.workspace = None
+        grads, off = [], 0
+        for shape in ctx.shapes:                  # views of the flat vector, state_dict order
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(grad[off:off + n].view(shape))
+            off += n
+        model.last_flat_grad = grad
+        return (None,) * 8 + tuple(grads)

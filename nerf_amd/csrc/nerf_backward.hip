@@ -1,0 +1,547 @@
+// Backward of the fused renderer w.r.t. the 22 parameter tensors (gfx950 only).  Replaces PyTorch
+// autograd through NeRF.render_rays (loss.backward(), train_conditional_nerf.py:133).  Three
+// launches, no atomics, bitwise reproducible:
+//   1. nerf_bwd_data_kernel  — per 16-sample chunk, last chunk of a ray first: compositing
+//      backward (model.py:438-469, :660-663) -> dL/d(out), then the data-gradient chain
+//      dX = W^T dY on fp32 MFMA with the transposed weight image streamed through LDS exactly
+//      like the forward, LayerNorm/ReLU backward in registers from the saved x_hat / 1/std.
+//      Writes dY of every layer (row order) for the weight gradients; gamma/beta gradients are
+//      row-reduced by DPP and summed per workgroup in LDS.
+//   2. nerf_wgrad_kernel     — dW_L = dY_L^T X_L as a split-K fp32 MFMA (32x32x2) GEMM over the
+//      padded samples; operands are staged [sample][feature] tiles moved by LDS-DMA; each
+//      workgroup writes a partial slab (and the bias partial = column sums of dY).
+//   3. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
+//      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
+#include "nerf_device.h"
+
+using namespace nerf_layout;
+using namespace nerf_device;
+
+namespace {
+
+constexpr int kGbFloats = 5 * 2 * kHidden;                         // gamma/beta partials per workgroup
+constexpr int kBwdLdsBytes = kSmallLdsBytes + kRing * kStageBytes + kGbFloats * 4;   // 74 KiB
+constexpr int kMaxSplits = 128;
+constexpr int kMaxDataGrid = 1024;
+
+// partial-slab layout (floats) for one split
+constexpr int kSlabW0 = 0;                                          // [256][96] kernel column order
+constexpr int kSlabWh = kSlabW0 + kHidden * kEncIn;                 // 4 x [256][256]
+constexpr int kSlabW5 = kSlabWh + 4 * kHidden * kHidden;            // [64][256]
+constexpr int kSlabB = kSlabW5 + kOutPad * kHidden;                 // 5 x [256] + [64]
+constexpr int kSlabFloats = kSlabB + 5 * kHidden + kOutPad;
+
+struct BwdArgs {
+    NerfHipRenderArgs a;
+    const float* d_rgb;
+    const float* d_seg;
+    int32_t intervals, chunks;
+    int64_t groups;
+    TrainLayout L;
+    float* gb_partial;          // [grid][5][2][256]
+    float* slabs;               // [splits][kSlabFloats]
+    float* grad;
+    int32_t splits, data_grid;
+    int64_t tiles_per_split, n_tiles;
+};
+
+typedef WeightPipe<kBwdStages> BwdPipe;
+
+// gamma/beta gradient partials of a workgroup live in LDS ([layer][gamma|beta][256]).  Each wave
+// row-reduces its 16 samples, then the four waves add their values in wave order, one wave per
+// stage barrier of the MFMA loop that follows (no atomics: bitwise reproducible).
+struct GammaBetaTurn {
+    float* dst;                 // this lane's 4 gamma slots; beta slots at +256
+    f32x4 kg, kb;
+    int wave;
+    __device__ __forceinline__ void operator()(int t) const {
+        if (t < kWavesPerWg && wave == t) {
+            f32x4* pg = (f32x4*)dst;
+            f32x4* pb = (f32x4*)(dst + kHidden);
+            *pg = *pg + kg;
+            *pb = *pb + kb;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // landed before the next barrier
+        }
+    }
+};
+
+// LayerNorm + ReLU backward for hidden layer L on the register tile.
+//   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
+//   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
+__device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
+                                                    f32x4 (&acc)[16], float (&act)[64],
+                                                    const float* xhat_tile, float rstd,
+                                                    float* dy_row, float* gb_l, GammaBetaTurn& turn) {
+    f32x4 xh[16];
+#pragma unroll
+    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_tile + T * 256);
+    const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
+    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const f32x4 ga = gam[T], be = bet[T];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = __builtin_fmaf(xh[T][r], ga[r], be[r]);
+            const float dz = z > 0.f ? acc[T][r] : 0.f;
+            // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
+            const float rb = row_sum(dz);
+            const float rg = row_sum(dz * xh[T][r]);
+            if (j == T) {
+                keep_b[r] = rb;
+                keep_g[r] = rg;
+            }
+            const float gdz = ga[r] * dz;
+            s1 += gdz;
+            s2 = __builtin_fmaf(gdz, xh[T][r], s2);
+            acc[T][r] = gdz;
+        }
+    }
+    turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
+    turn.kg = keep_g;
+    turn.kb = keep_b;
+    const float m1 = group_sum(s1) * (1.0f / 256.0f);
+    const float m2 = group_sum(s2) * (1.0f / 256.0f);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        f32x4 dy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dy[r] = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
+            act[4 * T + r] = dy[r];
+        }
+        *(f32x4*)(dy_row + T * 16) = dy;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int P = ba.intervals;
+    const int chunks = ba.chunks;
+    float* const ws = a.train_workspace;
+    float* const gb = (float*)(smem + kSmallLdsBytes + kRing * kStageBytes);
+
+    {
+        const float* small_g = a.packed + kBlobFloats;
+        float* small_l = (float*)smem;
+        for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
+        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+    }
+    const float* small = (const float*)smem;
+
+    const int64_t my_groups = ba.groups > (int64_t)blockIdx.x
+                                  ? (ba.groups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    BwdPipe pipe;
+    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, my_groups * chunks * kBwdStages, wave,
+              lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t slot = grp * kWavesPerWg + wave;
+        int64_t local = slot;
+        const bool ray_ok = local < a.n_rays;
+        if (!ray_ok) local = a.n_rays - 1;
+
+        // upstream gradients of this ray
+        const float g0 = ray_ok ? ba.d_rgb[local * 3 + 0] : 0.f;
+        const float g1 = ray_ok ? ba.d_rgb[local * 3 + 1] : 0.f;
+        const float g2 = ray_ok ? ba.d_rgb[local * 3 + 2] : 0.f;
+        const bool with_seg = ba.d_seg != nullptr;
+
+        float suffix = 0.f;                       // sum_{m in later chunks} q_m w_m
+        for (int c = chunks - 1; c >= 0; --c) {
+            const int s = c * kSamplesPerWave + j;
+            const bool ok = ray_ok && s < P;
+            const int64_t tile = slot * chunks + c;
+            const int64_t sp = tile * 16 + j;
+
+            // ---- compositing backward -> dL/d(out) in accumulator layout ----
+            f32x4 dout[4];
+            {
+                const f32x4 cmp = *(const f32x4*)(ws + ba.L.comp + sp * 4);   // alpha, T, dist, density
+                const float alpha = cmp.x, t_excl = cmp.y, dist = cmp.z, dens = cmp.w;
+                f32x4 out[4];
+                const float* otile = ws + ba.L.out + tile * 1024 + lane * 4;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
+                const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
+                // colour: logits on lane group 0 (slots 1..3)
+                const float sr = 1.0f / (1.0f + expf(-out[0].y));
+                const float sg = 1.0f / (1.0f + expf(-out[0].z));
+                const float sb = 1.0f / (1.0f + expf(-out[0].w));
+                float q = __shfl((g0 * sr + g1 * sg) + g2 * sb, j);           // dL/dw, colour part
+                // segmentation: v_sc = log(w + 1e-10) + log_softmax(x_s)[c]; seg_c = logsumexp_s v_sc
+                float m = 0.f, logz = 0.f, lw = 0.f, srho = 0.f;
+                float gseg[16], oseg[16];         // dL/dseg and forward seg of this lane's slots
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gseg[i] = oseg[i] = 0.f;
+                if (with_seg) {
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = 16 * T + 4 * g + r;
+                            if (ray_ok && n >= 4 && n < kOut) {
+                                gseg[4 * T + r] = ba.d_seg[local * kSegClasses + (n - 4)];
+                                oseg[4 * T + r] = a.seg[local * kSegClasses + (n - 4)];
+                            }
+                        }
+                    m = -__builtin_inff();
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
+                    m = group_max(m);
+                    float z = 0.f;
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (is_seg_slot(T, g, r)) z += expf(out[T][r] - m);
+                    logz = logf(group_sum(z));
+                    lw = logf(w + 1e-10f);
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (is_seg_slot(T, g, r)) {
+                                const float rho = expf(lw + ((out[T][r] - m) - logz) - oseg[4 * T + r]);
+                                srho = __builtin_fmaf(gseg[4 * T + r], rho, srho);
+                            }
+                    srho = ok ? group_sum(srho) : 0.f;
+                    q += srho / (w + 1e-10f);
+                }
+                const float qw = ok ? q * w : 0.f;
+                const float suf_incl = row_suffix_sum(qw);
+                const float suf_excl = suffix + row_shift_down(0.f, suf_incl);
+                suffix += __shfl(suf_incl, lane & 48);
+                const float dalpha = -q * t_excl + suf_excl / (alpha + 1e-10f);
+                const float dsigma = (ok && dens > 0.f) ? dalpha * (-dist * alpha) : 0.f;
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 16 * T + 4 * g + r;
+                        float v = 0.f;
+                        if (n >= 4 && n < kOut && with_seg) {
+                            const float lp = (out[T][r] - m) - logz;
+                            const float rho = expf(lw + lp - oseg[4 * T + r]);
+                            v = gseg[4 * T + r] * rho - expf(lp) * srho;
+                        }
+                        dout[T][r] = v;
+                    }
+                if (g == 0) {
+                    dout[0].x = dsigma;
+                    dout[0].y = g0 * w * sr * (1.0f - sr);
+                    dout[0].z = g1 * w * sg * (1.0f - sg);
+                    dout[0].w = g2 * w * sb * (1.0f - sb);
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) dout[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) *(f32x4*)(drow + T * 16) = dout[T];
+            }
+
+            // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
+#pragma unroll
+            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < kStagesL5; ++t) {
+                const f32x4* st = pipe.begin_stage();
+                turn(t);                          // layer-0 partials of the previous chunk
+                stage_wide(st, acc, dout[t].x, dout[t].y, dout[t].z, dout[t].w);
+            }
+            // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
+#pragma unroll 1
+            for (int L = 4; L >= 1; --L) {
+                layer_norm_relu_bwd(small + L * kSmallPerLayer, g, j, acc, act,
+                                    ws + ba.L.xhat[L] + tile * 4096 + lane * 4,
+                                    ws[ba.L.rstd[L] + sp],
+                                    ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
+#pragma unroll
+                for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                layer_wide<kStagesHidden>(pipe, acc, act, turn);
+            }
+            layer_norm_relu_bwd(small, g, j, acc, act, ws + ba.L.xhat[0] + tile * 4096 + lane * 4,
+                                ws[ba.L.rstd[0] + sp], ws + ba.L.dy[0] + sp * kHidden + 4 * g, gb, turn);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < kWavesPerWg; ++t) {       // the last chunk's layer-0 partials, in wave order
+        __syncthreads();
+        turn(t);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients: dW[out][in] = sum_s dY[s][out] X[s][in], split over sample tiles
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKs = 32;                          // samples per LDS tile
+
+template <int OUT_W, int IN_W, int TO, int TI>
+struct WgradShape {
+    static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
+    static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
+    static constexpr int kTileBytes = kDyBytes + kXBytes;
+    static constexpr int kPieces = kTileBytes / 1024;          // 1 KiB LDS-DMA pieces per tile
+    static constexpr int kPiecesPerWave = kPieces / 4;
+    static_assert(kPieces % 4 == 0, "pieces must split over 4 waves");
+};
+typedef WgradShape<kHidden, kEncIn, 2, 3> ShapeL0;        // waves: out tiles 2w..2w+1, all 3 in tiles
+typedef WgradShape<kHidden, kHidden, 4, 4> ShapeHid;       // waves 2x2: 4x4 tiles each
+typedef WgradShape<kOutPad, kHidden, 2, 2> ShapeL5;        // waves: both out tiles, in tiles 2w..2w+1
+
+template <class Sh>
+__device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int64_t sample0,
+                                            char* buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < Sh::kPiecesPerWave; ++i) {
+        const int piece = wave * Sh::kPiecesPerWave + i;
+        const int byte = piece * 1024;
+        const char* src = byte < Sh::kDyBytes
+                              ? (const char*)(dy + sample0 * Sh::kOutW) + byte
+                              : (const char*)(x + sample0 * Sh::kInW) + (byte - Sh::kDyBytes);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(buf + byte), 16, 0, 0);
+    }
+}
+
+template <class Sh>
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba, const float* dy,
+                                                            const float* x, int w_off, int b_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x;
+    // hidden layers share one launch: blockIdx.y selects the layer
+    dy += (int64_t)blockIdx.y * ba.L.mp * kHidden;
+    x += (int64_t)blockIdx.y * ba.L.mp * kHidden;
+    w_off += blockIdx.y * kHidden * kHidden;
+    b_off += blockIdx.y * kHidden;
+
+    int out0, in0;                                // first 32-wide tile of this wave
+    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
+    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
+    else { out0 = 0; in0 = 2 * wave; }
+
+    f32x16 acc[Sh::kTo][Sh::kTi];
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bias_sum = 0.f;
+
+    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
+    int64_t tile_end = tile_begin + ba.tiles_per_split;
+    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
+    const int64_t nt = tile_end > tile_begin ? tile_end - tile_begin : 0;
+
+    if (nt > 0) wgrad_issue<Sh>(dy, x, tile_begin * kKs, smem, wave, lane);
+    for (int64_t k = 0; k < nt; ++k) {
+        char* cur = smem + (k & 1) * Sh::kTileBytes;
+        if (k + 1 < nt) {
+            wgrad_issue<Sh>(dy, x, (tile_begin + k + 1) * kKs, smem + ((k + 1) & 1) * Sh::kTileBytes,
+                            wave, lane);
+            if (Sh::kPiecesPerWave == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (Sh::kPiecesPerWave == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* dyt = (const float*)cur;
+        const float* xt = (const float*)(cur + Sh::kDyBytes);
+        const int i = lane & 31, kk = lane >> 5;
+#pragma unroll 4
+        for (int step = 0; step < kKs / 2; ++step) {
+            const int srow = 2 * step + kk;
+            float af[Sh::kTo], bf[Sh::kTi];
+#pragma unroll
+            for (int a = 0; a < Sh::kTo; ++a) af[a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
+#pragma unroll
+            for (int b = 0; b < Sh::kTi; ++b) bf[b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
+#pragma unroll
+            for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+                for (int b = 0; b < Sh::kTi; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if ((int)threadIdx.x < Sh::kOutW) {       // bias gradient: column sums of dY
+#pragma unroll 8
+            for (int srow = 0; srow < kKs; ++srow) bias_sum += dyt[srow * Sh::kOutW + threadIdx.x];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r];
+            }
+    if ((int)threadIdx.x < Sh::kOutW) slab[b_off + threadIdx.x] = bias_sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic reduction of the partials into the flat gradient vector
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int layer0_kernel_column(int feature) {
+    // inverse of nerf_layout::layer0_source_feature
+    const int part = feature / 48, rem = feature % 48;
+    const int scale = rem / 3, coord = rem % 3;
+    const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
+    return 16 * (q / 4) + 4 * g + (q % 4);
+}
+
+__global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kGradElements) return;
+    // locate e: tensor index in state_dict order
+    int tensor = 0, off = 0;
+    for (;;) {
+        const int L = tensor / 4, which = tensor % 4;
+        const int n = which == 0 ? (L == 0 ? kHidden * kEncIn : (L == 5 ? kOut * kHidden : kHidden * kHidden))
+                                 : (L == 5 ? kOut : kHidden);
+        if (e < off + n) break;
+        off += n;
+        ++tensor;
+    }
+    const int idx = e - off, L = tensor / 4, which = tensor % 4;
+    float sum = 0.f;
+    if (which >= 2) {                             // gamma (2) / beta (3): per-workgroup partials
+        const float* p = ba.gb_partial + L * 2 * kHidden + (which - 2) * kHidden + idx;
+        for (int w = 0; w < ba.data_grid; ++w) sum += p[(int64_t)w * kGbFloats];
+    } else {
+        int so;
+        if (which == 0) {
+            if (L == 0) so = kSlabW0 + (idx / kEncIn) * kEncIn + layer0_kernel_column(idx % kEncIn);
+            else if (L == 5) so = kSlabW5 + idx;
+            else so = kSlabWh + (L - 1) * kHidden * kHidden + idx;
+        } else {
+            so = kSlabB + L * kHidden + idx;
+        }
+        const float* p = ba.slabs + so;
+        for (int s = 0; s < ba.splits; ++s) sum += p[(int64_t)s * kSlabFloats];
+    }
+    ba.grad[e] = sum;
+}
+
+int choose_splits(int64_t n_tiles) {
+    int64_t s = n_tiles / 8;
+    if (s < 1) s = 1;
+    if (s > kMaxSplits) s = kMaxSplits;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
+    if (n_rays <= 0 || num_samples < 2) return 0;
+    return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * kGbFloats) * sizeof(float);
+}
+
+int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
+    if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: null args");
+    const NerfHipRenderArgs& a = args->fwd;
+    if (args->grad == nullptr || args->scratch == nullptr || args->d_rgb == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad / scratch / d_rgb is null");
+    if (a.train_workspace == nullptr || a.packed == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: forward was not a training forward");
+    if (args->d_seg != nullptr && a.seg == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: d_seg given but forward seg is null");
+    if (a.n_rays <= 0 || a.num_samples < 2 || a.num_samples > 4096)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: n_rays / num_samples out of range");
+    hipStream_t st = (hipStream_t)stream;
+
+    BwdArgs ba;
+    ba.a = a;
+    ba.d_rgb = args->d_rgb;
+    ba.d_seg = args->d_seg;
+    ba.intervals = a.num_samples - 1;
+    ba.chunks = (ba.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
+    ba.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+    ba.L = make_train_layout(a.n_rays, ba.chunks);
+    ba.grad = args->grad;
+    ba.n_tiles = ba.L.mp / kKs;
+    ba.splits = choose_splits(ba.n_tiles);
+    ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
+    ba.slabs = args->scratch;
+    ba.gb_partial = args->scratch + (size_t)kMaxSplits * kSlabFloats;
+
+    int device = 0, cus = 0;
+    int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
+    if (rc) return rc;
+    rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
+                                "hipDeviceGetAttribute");
+    if (rc) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[4] = {(const void*)nerf_bwd_data_kernel, (const void*)nerf_wgrad_kernel<ShapeL0>,
+                              (const void*)nerf_wgrad_kernel<ShapeHid>, (const void*)nerf_wgrad_kernel<ShapeL5>};
+        const int lds[4] = {kBwdLdsBytes, 2 * ShapeL0::kTileBytes, 2 * ShapeHid::kTileBytes,
+                            2 * ShapeL5::kTileBytes};
+        for (int i = 0; i < 4; ++i) {
+            rc = nerf_common::check_hip(
+                hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds[i]),
+                "hipFuncSetAttribute");
+            if (rc) return rc;
+        }
+        attr_set = true;
+    }
+    int64_t grid = (int64_t)cus * 2;
+    if (grid > ba.groups) grid = ba.groups;
+    if (grid > kMaxDataGrid) grid = kMaxDataGrid;
+    ba.data_grid = (int)grid;
+
+    float* ws = a.train_workspace;
+    hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeHid>, dim3(ba.splits, 4), dim3(256), 2 * ShapeHid::kTileBytes,
+                       st, ba, (const float*)(ws + ba.L.dy[1]), (const float*)(ws + ba.L.x[0]), kSlabWh,
+                       kSlabB + kHidden);
+    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeL0>, dim3(ba.splits, 1), dim3(256), 2 * ShapeL0::kTileBytes, st,
+                       ba, (const float*)(ws + ba.L.dy[0]), (const float*)(ws + ba.L.h), kSlabW0, kSlabB);
+    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeL5>, dim3(ba.splits, 1), dim3(256), 2 * ShapeL5::kTileBytes, st,
+                       ba, (const float*)(ws + ba.L.dy5), (const float*)(ws + ba.L.x[4]), kSlabW5,
+                       kSlabB + 5 * kHidden);
+    const int threads = 256;
+    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((kGradElements + threads - 1) / threads), dim3(threads),
+                       0, st, ba);
+    return nerf_common::check_hip(hipGetLastError(), "render_backward launch");
+}
+
+}  // extern "C"

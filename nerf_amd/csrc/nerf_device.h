@@ -1,0 +1,326 @@
+// Device-side building blocks shared by the forward and backward kernels (gfx950 only):
+// the LDS-DMA weight pipe, fp32 MFMA layer loops, DPP row reductions/scans, and the unfused
+// fp32 front end (ray, fenceposts, frustum Gaussian, integrated positional encoding).
+#ifndef NERF_DEVICE_H
+#define NERF_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerf_hip.h"
+#include "nerf_layout.h"
+#include "nerf_common.h"
+
+namespace nerf_device {
+
+using namespace nerf_layout;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRing = 3;                        // LDS ring slots (one 16 KiB stage each)
+constexpr int kSmallLdsBytes = 16384;           // small image (15,616 B) padded
+constexpr int kWavesPerWg = 4;
+constexpr int kSamplesPerWave = 16;
+
+// ---------------------------------------------------------------------------------------------
+// saved-for-backward workspace (training forward writes it, backward reads/extends it)
+// padded sample index sp = (ray * chunks + c) * 16 + j ; "tile" tensors are stored exactly in
+// register order [chunk][T][lane][r] (1 KiB per store instruction), "row" tensors as
+// [sp][feature] (what the weight-gradient GEMM stages through LDS).
+// ---------------------------------------------------------------------------------------------
+struct TrainLayout {
+    int64_t mp;                 // padded samples = ceil4(n_rays) * chunks * 16
+    int64_t h;                  // row  [mp, 96]   encoded inputs, kernel column order
+    int64_t x[5];               // row  [mp, 256]  input of layer L+1 (post LayerNorm+ReLU)
+    int64_t dy[5];              // row  [mp, 256]  grad wrt pre-LayerNorm output of layer L
+    int64_t dy5;                // row  [mp, 64]   grad wrt padded network output
+    int64_t xhat[5];            // tile [mp, 256]  normalised pre-affine activations
+    int64_t rstd[5];            // [mp]
+    int64_t out;                // tile [mp, 64]   padded network output
+    int64_t comp;               // [mp, 4]         alpha, T_exclusive, dist, density(+noise)
+    int64_t total;              // floats
+};
+
+__host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chunks) {
+    TrainLayout t;
+    const int64_t rays4 = (n_rays + 3) / 4 * 4;
+    t.mp = rays4 * chunks * 16;
+    int64_t off = 0;
+    t.h = off; off += t.mp * kEncIn;
+    for (int i = 0; i < 5; ++i) { t.x[i] = off; off += t.mp * kHidden; }
+    for (int i = 0; i < 5; ++i) { t.dy[i] = off; off += t.mp * kHidden; }
+    t.dy5 = off; off += t.mp * kOutPad;
+    for (int i = 0; i < 5; ++i) { t.xhat[i] = off; off += t.mp * kHidden; }
+    for (int i = 0; i < 5; ++i) { t.rstd[i] = off; off += t.mp; }
+    t.out = off; off += t.mp * kOutPad;
+    t.comp = off; off += t.mp * 4;
+    t.total = off;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight stream: global -> LDS by LDS-DMA, two stages ahead of the MFMAs
+// ---------------------------------------------------------------------------------------------
+template <int kStagesInImage>
+struct WeightPipe {
+    const char* blob;           // packed image, stage 0
+    char* ring;                 // LDS ring base
+    int64_t to_issue;           // stages still to be issued by this workgroup
+    int issue_stage;            // next stage of the image to issue (cyclic)
+    int issue_slot;             // ring slot it goes to
+    int read_slot;              // ring slot of the stage being consumed
+    int wave;                   // wave id in the workgroup (uniform)
+    int lane;
+
+    __device__ __forceinline__ void init(const void* image, char* lds_ring, int64_t stages, int w,
+                                         int l) {
+        blob = (const char*)image;
+        ring = lds_ring;
+        to_issue = stages;
+        issue_stage = issue_slot = read_slot = 0;
+        wave = w;
+        lane = l;
+    }
+
+    __device__ __forceinline__ void issue() {
+        if (to_issue > 0) {
+            const char* src = blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16;
+            char* dst = ring + issue_slot * kStageBytes + wave * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + i * 1024),
+                    (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+            --to_issue;
+        }
+        issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;
+        issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
+    }
+
+    // Top of a stage: this wave's DMA pieces of the stage have landed (the 4 youngest = the next
+    // stage may still fly; any other younger vector-memory op only makes the wait conservative),
+    // every wave has passed the barrier, so (a) all 16 pieces are visible and (b) nobody still
+    // reads the slot the next issue overwrites.
+    __device__ __forceinline__ const f32x4* begin_stage() {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
+        read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
+        return p;
+    }
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// One 16 KiB stage against 16 output tiles: k-group values b0..b3 (this lane's B operands).
+__device__ __forceinline__ void stage_wide(const f32x4* st, f32x4 (&acc)[16], float b0, float b1,
+                                           float b2, float b3) {
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {
+        const f32x4 a0 = st[(2 * tp) * 64];
+        const f32x4 a1 = st[(2 * tp + 1) * 64];
+        acc[2 * tp] = mfma4(a0.x, b0, acc[2 * tp]);
+        acc[2 * tp + 1] = mfma4(a1.x, b0, acc[2 * tp + 1]);
+        acc[2 * tp] = mfma4(a0.y, b1, acc[2 * tp]);
+        acc[2 * tp + 1] = mfma4(a1.y, b1, acc[2 * tp + 1]);
+        acc[2 * tp] = mfma4(a0.z, b2, acc[2 * tp]);
+        acc[2 * tp + 1] = mfma4(a1.z, b2, acc[2 * tp + 1]);
+        acc[2 * tp] = mfma4(a0.w, b3, acc[2 * tp]);
+        acc[2 * tp + 1] = mfma4(a1.w, b3, acc[2 * tp + 1]);
+    }
+}
+
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+// hook(t) runs right after the barrier that opens stage t (every wave has passed it)
+template <int KT, class Pipe, class Hook = NoHook>
+__device__ __forceinline__ void layer_wide(Pipe& pipe, f32x4 (&acc)[16], const float (&act)[64],
+                                           Hook hook = Hook()) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const f32x4* st = pipe.begin_stage();
+        hook(t);
+        stage_wide(st, acc, act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane: lane = 16 g + j ; rows of 16 lanes (one DPP row) are the samples, g the feature group
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp(float old, float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                           CTRL, 0xf, 0xf, false));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
+
+// sum / max over the 16 lanes of a row, result in every lane of the row
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp<kQuadXor1>(0.f, v);
+    v += dpp<kQuadXor2>(0.f, v);
+    v += dpp<kRowHalfMirror>(0.f, v);
+    v += dpp<kRowMirror>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+    v = __builtin_fmaxf(v, dpp<kQuadXor1>(v, v));
+    v = __builtin_fmaxf(v, dpp<kQuadXor2>(v, v));
+    v = __builtin_fmaxf(v, dpp<kRowHalfMirror>(v, v));
+    v = __builtin_fmaxf(v, dpp<kRowMirror>(v, v));
+    return v;
+}
+// inclusive prefix product along the row (lane j gets x_0 * ... * x_j)
+__device__ __forceinline__ float row_prefix_prod(float v) {
+    v *= dpp<0x111>(1.0f, v);
+    v *= dpp<0x112>(1.0f, v);
+    v *= dpp<0x114>(1.0f, v);
+    v *= dpp<0x118>(1.0f, v);
+    return v;
+}
+// inclusive suffix sum along the row (lane j gets x_j + ... + x_15)
+__device__ __forceinline__ float row_suffix_sum(float v) {
+    v += dpp<0x101>(0.f, v);
+    v += dpp<0x102>(0.f, v);
+    v += dpp<0x104>(0.f, v);
+    v += dpp<0x108>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float row_shift_up(float fill, float v) { return dpp<0x111>(fill, v); }    // from j-1
+__device__ __forceinline__ float row_shift_down(float fill, float v) { return dpp<0x101>(fill, v); }  // from j+1
+
+__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups of a sample
+    v += xor16(v);
+    v += xor32(v);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+    v = __builtin_fmaxf(v, xor16(v));
+    v = __builtin_fmaxf(v, xor32(v));
+    return v;
+}
+
+// Output slot n = 16 T + 4 g + reg of the padded last layer: 0 density, 1..3 color,
+// 4..53 segmentation classes, 54..63 padding (nerf/model.py:591-592).
+__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg) {
+    const int n = 16 * T + 4 * g + reg;
+    return n >= 4 && n < kOut;
+}
+
+// ---------------------------------------------------------------------------------------------
+// front end: ray, fenceposts, Gaussian, IPE  (all fp32, unfused like the reference's ATen ops)
+// ---------------------------------------------------------------------------------------------
+struct Ray {
+    float o[3], d[3];
+};
+
+__device__ __forceinline__ Ray load_ray(const NerfHipRenderArgs& a, int64_t local) {
+#pragma clang fp contract(off)
+    Ray r;
+    if (a.rays_o != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.o[k] = a.rays_o[local * 3 + k];
+            r.d[k] = a.rays_d[local * 3 + k];
+        }
+    } else {
+        // nerf/model.py:271-278 (pixel grid, ij indexing) and :367 (R . ray, summed left to right)
+        const int64_t gid = a.ray_begin + local;
+        const int64_t hw = (int64_t)a.image_h * a.image_w;
+        const int64_t b = gid / hw;
+        const int64_t pix = gid - b * hw;
+        const int row = (int)(pix / a.image_w), col = (int)(pix - (int64_t)row * a.image_w);
+        const float x = ((float)col - 0.5f * (float)(a.image_w - 1)) / a.focal_length;
+        const float y = ((float)row - 0.5f * (float)(a.image_h - 1)) / a.focal_length;
+        const float c0 = x, c1 = -y, c2 = -1.0f;
+        const float* R = a.camera_r + b * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.d[k] = (R[3 * k] * c0 + R[3 * k + 1] * c1) + R[3 * k + 2] * c2;
+            r.o[k] = a.camera_o[b * 3 + k];
+        }
+    }
+    return r;
+}
+
+// Fencepost s of a ray (nerf/model.py:414-435), s clamped to the table.
+__device__ __forceinline__ float fencepost(const NerfHipRenderArgs& a, int64_t local, int s) {
+#pragma clang fp contract(off)
+    const int S = a.num_samples;
+    s = s < S - 1 ? s : S - 1;
+    if (a.t_values != nullptr) return a.t_values[local * S + s];
+    const float cur = a.t_table[s];
+    float t = cur;
+    const bool draw = (a.rng_mode & 1) != 0;
+    if (a.u != nullptr || draw) {
+        const float lower = s == 0 ? cur : 0.5f * (cur + a.t_table[s - 1]);
+        const float upper = s == S - 1 ? cur : 0.5f * (a.t_table[s + 1] + cur);
+        const float uu = a.u != nullptr ? a.u[local * S + s]
+                                        : nerf_rng::uniform(a.rng_seed, a.rng_offset,
+                                                            (uint64_t)(a.ray_begin + local), (uint32_t)s, 0u);
+        t = lower + (upper - lower) * uu;
+    }
+    return t * a.t_scale;
+}
+
+struct Gaussian {
+    float mean[3], cov[3];
+};
+
+// conical_frustum_to_gaussian(stable) + lift_gaussian(diag) + origin shift.
+__device__ __forceinline__ Gaussian frustum(const Ray& r, float t0, float t1, float base_radius_sq) {
+#pragma clang fp contract(off)
+    const float c415 = (float)(4.0 / 15.0), c512 = (float)(5.0 / 12.0);
+    const float mu = (t0 + t1) / 2.0f;
+    const float hw = (t1 - t0) / 2.0f;
+    const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+    const float denom = 3.0f * mu2 + hw2;
+    const float t_mean = mu + (2.0f * mu * hw2) / denom;
+    const float t_var = hw2 / 3.0f - c415 * ((hw4 * (12.0f * mu2 - hw2)) / (denom * denom));
+    const float r_var = base_radius_sq * ((mu2 / 4.0f + c512 * hw2) - (c415 * hw4) / denom);
+    const float d0 = r.d[0] * r.d[0], d1 = r.d[1] * r.d[1], d2 = r.d[2] * r.d[2];
+    const float mag = __builtin_fmaxf((d0 + d1) + d2, 1e-10f);
+    const float dsq[3] = {d0, d1, d2};
+    Gaussian g;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.mean[k] = r.d[k] * t_mean + r.o[k];
+        g.cov[k] = t_var * dsq[k] + r_var * (1.0f - dsq[k] / mag);
+    }
+    return g;
+}
+
+// 24 encoded features of this lane group (layout: nerf_layout.h).
+__device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[64]) {
+#pragma clang fp contract(off)
+    const float base = __builtin_ldexpf(1.0f, 4 * g - 4);       // 2^(4g-4): scales 4g..4g+3 of -4..11
+    const float half_pi = 1.5707963267948966f;
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+        const float scale = base * (float)(1 << (p / 3));
+        const float y = gs.mean[p % 3] * scale;
+        const float yv = gs.cov[p % 3] * (scale * scale);
+        const float damp = expf(-0.5f * yv);
+        act[p] = damp * sinf(y);
+        act[12 + p] = damp * sinf(y + half_pi);
+    }
+}
+
+// distance between the means of consecutive Gaussians (nerf/model.py:462-464)
+__device__ __forceinline__ float mean_distance(const Gaussian& a, const Gaussian& b) {
+#pragma clang fp contract(off)
+    const float e0 = b.mean[0] - a.mean[0], e1 = b.mean[1] - a.mean[1], e2 = b.mean[2] - a.mean[2];
+    return __builtin_sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+}
+
+}  // namespace nerf_device
+#endif

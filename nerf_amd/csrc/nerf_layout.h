@@ -41,7 +41,29 @@ constexpr int kBlobFloats = kNumStages * kStageFloats;
 
 constexpr int kSmallPerLayer = 3 * kHidden;       // bias, gamma, beta
 constexpr int kSmallFloats = 5 * kSmallPerLayer + kOutPad;   // 3904
-constexpr int kPackedFloats = kBlobFloats + kSmallFloats;
+// Transposed image for the data-gradient chain (dX = W^T dY), consumed last layer first:
+//   stages 0..3   : layer 5, stage = k-group of OUT features tout (64 padded outs)
+//   stages 4..67  : layers 4, 3, 2, 1, 16 stages each, stage = tout
+// quad = in-tile Tin (16 of them), [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i].
+constexpr int kBwdStages = kStagesL5 + 4 * kStagesHidden;               // 68
+constexpr int kBwdBlobFloats = kBwdStages * kStageFloats;
+constexpr int kBwdBlobOffset = kBlobFloats + kSmallFloats;              // 16-byte aligned
+constexpr int kPackedFloats = kBlobFloats + kSmallFloats + kBwdBlobFloats;
+
+// flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts
+constexpr int kGradElements = kHidden * kEncIn + kHidden + 2 * kHidden
+                              + 4 * (kHidden * kHidden + kHidden + 2 * kHidden)
+                              + kOut * kHidden + kOut;                  // 304,438
+__host__ __device__ inline int grad_offset(int tensor) {
+    // tensor index in state_dict order: 4 L + {0 W, 1 b, 2 gamma, 3 beta} for L < 5; 20 W5, 21 b5
+    int off = 0;
+    for (int i = 0; i < tensor; ++i) {
+        const int L = i / 4, which = i % 4;
+        if (which == 0) off += (L == 0 ? kHidden * kEncIn : (L == 5 ? kOut * kHidden : kHidden * kHidden));
+        else off += (L == 5 ? kOut : kHidden);
+    }
+    return off;
+}
 
 // Input-feature permutation of layer 0: lane group g computes, for the Gaussian of its sample,
 // the 12 (scale, coord) pairs with scale index 4 g .. 4 g + 3; local slot q = 4 t + r:

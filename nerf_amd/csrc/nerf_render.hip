@@ -8,107 +8,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "nerf_hip.h"
-#include "nerf_layout.h"
-#include "nerf_common.h"
+#include "nerf_device.h"
 
 using namespace nerf_layout;
+using namespace nerf_device;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kRing = 3;                        // LDS ring slots (one stage each)
-constexpr int kSmallLdsBytes = 16384;           // small image (15,616 B) padded
 constexpr int kLdsBytes = kSmallLdsBytes + kRing * kStageBytes;   // 64 KiB -> 2 workgroups / CU
-constexpr int kWavesPerWg = 4;
-constexpr int kSamplesPerWave = 16;
 
 struct KernelArgs {
     NerfHipRenderArgs a;
     int32_t intervals;          // P = S - 1
     int32_t chunks;             // ceil(P / 16)
     int64_t groups;             // ceil(n_rays / 4)
+    TrainLayout save;           // offsets into a.train_workspace (training forward only)
 };
 
-// ---------------------------------------------------------------------------------------------
-// weight stream: global -> LDS by LDS-DMA, two stages ahead of the MFMAs
-// ---------------------------------------------------------------------------------------------
-struct WeightPipe {
-    const char* blob;           // packed image, stage 0
-    char* ring;                 // LDS ring base
-    int64_t to_issue;           // stages still to be issued by this workgroup
-    int issue_stage;            // next stage of the image to issue (0..73, cyclic)
-    int issue_slot;             // ring slot it goes to
-    int read_slot;              // ring slot of the stage being consumed
-    int wave;                   // wave id in the workgroup (uniform)
-    int lane;
-
-    __device__ __forceinline__ void issue() {
-        if (to_issue > 0) {
-            const char* src = blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16;
-            char* dst = ring + issue_slot * kStageBytes + wave * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + i * 1024),
-                    (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-            }
-            --to_issue;
-        }
-        issue_stage = (issue_stage + 1 == kNumStages) ? 0 : issue_stage + 1;
-        issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
-    }
-
-    // Top of a stage: own DMA pieces of this stage have landed (the 4 youngest = next stage
-    // may still fly), every wave has passed the barrier, so (a) all 16 pieces are visible and
-    // (b) nobody still reads the slot the next issue overwrites.
-    __device__ __forceinline__ const f32x4* begin_stage() {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue();
-        const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
-        read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
-        return p;
-    }
-};
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// One 16 KiB stage of a 16-out-tile layer: k-group t against all 16 out tiles.
-__device__ __forceinline__ void stage_wide(const f32x4* st, f32x4 (&acc)[16], float b0, float b1,
-                                           float b2, float b3) {
-#pragma unroll
-    for (int tp = 0; tp < 8; ++tp) {
-        const f32x4 a0 = st[(2 * tp) * 64];
-        const f32x4 a1 = st[(2 * tp + 1) * 64];
-        acc[2 * tp] = mfma4(a0.x, b0, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.x, b0, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.y, b1, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.y, b1, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.z, b2, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.z, b2, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.w, b3, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.w, b3, acc[2 * tp + 1]);
-    }
-}
-
-template <int KT>
-__device__ __forceinline__ void layer_wide(WeightPipe& pipe, f32x4 (&acc)[16],
-                                           const float (&act)[64]) {
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        const f32x4* st = pipe.begin_stage();
-        stage_wide(st, acc, act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
-    }
-}
+typedef WeightPipe<kNumStages> FwdPipe;
 
 // Layer 5 (256 -> 64 padded): 4 stages, each 4 k-groups x 4 out tiles.
-__device__ __forceinline__ void layer_out(WeightPipe& pipe, f32x4 (&acc)[4],
-                                          const float (&act)[64]) {
+__device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&acc)[4], const float (&act)[64]) {
 #pragma unroll
     for (int s = 0; s < kStagesL5; ++s) {
         const f32x4* st = pipe.begin_stage();
@@ -139,19 +59,18 @@ __device__ __forceinline__ void layer_out(WeightPipe& pipe, f32x4 (&acc)[4],
     }
 }
 
-__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
-
 // LayerNorm(256, eps 1e-5, affine, biased variance) + ReLU on the accumulator tile, result
 // written as the next layer's B operands.  A sample's 256 features sit in 64 registers of
-// each of the 4 lanes {j, j+16, j+32, j+48}.
+// each of the 4 lanes {j, j+16, j+32, j+48}.  Training also saves x_hat (register order),
+// the post-ReLU activations (row order, for the weight-gradient GEMM) and 1/std.
+template <bool kTrain>
 __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, const f32x4 (&acc)[16],
-                                                float (&act)[64]) {
+                                                float (&act)[64], float* save_xhat_tile,
+                                                float* save_x_row, float* save_rstd) {
     float s = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
-    s += xor16(s);
-    s += xor32(s);
+    s = group_sum(s);
     const float mean = s * (1.0f / 256.0f);
     float v = 0.f;
 #pragma unroll
@@ -162,20 +81,26 @@ __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, con
             v = __builtin_fmaf(d, d, v);
         }
     }
-    v += xor16(v);
-    v += xor32(v);
+    v = group_sum(v);
     const float rstd = 1.0f / __builtin_sqrtf(v * (1.0f / 256.0f) + 1e-5f);
     const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
     const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
         const f32x4 ga = gam[T], be = bet[T];
+        f32x4 xh, xo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float y = __builtin_fmaf((acc[T][r] - mean) * rstd, ga[r], be[r]);
-            act[4 * T + r] = __builtin_fmaxf(y, 0.f);
+            xh[r] = (acc[T][r] - mean) * rstd;
+            xo[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
+            act[4 * T + r] = xo[r];
+        }
+        if (kTrain) {
+            *(f32x4*)(save_xhat_tile + T * 256) = xh;
+            *(f32x4*)(save_x_row + T * 16) = xo;
         }
     }
+    if (kTrain && g == 0) *save_rstd = rstd;
 }
 
 __device__ __forceinline__ void load_bias16(const float* small_l, int g, f32x4 (&acc)[16]) {
@@ -185,132 +110,9 @@ __device__ __forceinline__ void load_bias16(const float* small_l, int g, f32x4 (
 }
 
 // ---------------------------------------------------------------------------------------------
-// front end: ray, fenceposts, Gaussian, IPE  (all fp32, unfused like the reference's ATen ops)
-// ---------------------------------------------------------------------------------------------
-struct Ray {
-    float o[3], d[3];
-};
-
-__device__ __forceinline__ Ray load_ray(const NerfHipRenderArgs& a, int64_t local) {
-#pragma clang fp contract(off)
-    Ray r;
-    if (a.rays_o != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.o[k] = a.rays_o[local * 3 + k];
-            r.d[k] = a.rays_d[local * 3 + k];
-        }
-    } else {
-        // nerf/model.py:271-278 (pixel grid, ij indexing) and :367 (R . ray, summed left to right)
-        const int64_t gid = a.ray_begin + local;
-        const int64_t hw = (int64_t)a.image_h * a.image_w;
-        const int64_t b = gid / hw;
-        const int64_t pix = gid - b * hw;
-        const int row = (int)(pix / a.image_w), col = (int)(pix - (int64_t)row * a.image_w);
-        const float x = ((float)col - 0.5f * (float)(a.image_w - 1)) / a.focal_length;
-        const float y = ((float)row - 0.5f * (float)(a.image_h - 1)) / a.focal_length;
-        const float c0 = x, c1 = -y, c2 = -1.0f;
-        const float* R = a.camera_r + b * 9;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.d[k] = (R[3 * k] * c0 + R[3 * k + 1] * c1) + R[3 * k + 2] * c2;
-            r.o[k] = a.camera_o[b * 3 + k];
-        }
-    }
-    return r;
-}
-
-// Fencepost s of a ray (nerf/model.py:414-435), s clamped to the table.
-__device__ __forceinline__ float fencepost(const NerfHipRenderArgs& a, int64_t local, int s) {
-#pragma clang fp contract(off)
-    const int S = a.num_samples;
-    s = s < S - 1 ? s : S - 1;
-    if (a.t_values != nullptr) return a.t_values[local * S + s];
-    const float cur = a.t_table[s];
-    float t = cur;
-    const bool draw = (a.rng_mode & 1) != 0;
-    if (a.u != nullptr || draw) {
-        const float lower = s == 0 ? cur : 0.5f * (cur + a.t_table[s - 1]);
-        const float upper = s == S - 1 ? cur : 0.5f * (a.t_table[s + 1] + cur);
-        const float uu = a.u != nullptr ? a.u[local * S + s]
-                                        : nerf_rng::uniform(a.rng_seed, a.rng_offset,
-                                                            (uint64_t)(a.ray_begin + local), (uint32_t)s, 0u);
-        t = lower + (upper - lower) * uu;
-    }
-    return t * a.t_scale;
-}
-
-struct Gaussian {
-    float mean[3], cov[3];
-};
-
-// conical_frustum_to_gaussian(stable) + lift_gaussian(diag) + origin shift.
-__device__ __forceinline__ Gaussian frustum(const Ray& r, float t0, float t1, float base_radius_sq) {
-#pragma clang fp contract(off)
-    const float c415 = (float)(4.0 / 15.0), c512 = (float)(5.0 / 12.0);
-    const float mu = (t0 + t1) / 2.0f;
-    const float hw = (t1 - t0) / 2.0f;
-    const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
-    const float denom = 3.0f * mu2 + hw2;
-    const float t_mean = mu + (2.0f * mu * hw2) / denom;
-    const float t_var = hw2 / 3.0f - c415 * ((hw4 * (12.0f * mu2 - hw2)) / (denom * denom));
-    const float r_var = base_radius_sq * ((mu2 / 4.0f + c512 * hw2) - (c415 * hw4) / denom);
-    const float d0 = r.d[0] * r.d[0], d1 = r.d[1] * r.d[1], d2 = r.d[2] * r.d[2];
-    const float mag = __builtin_fmaxf((d0 + d1) + d2, 1e-10f);
-    const float dsq[3] = {d0, d1, d2};
-    Gaussian g;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        g.mean[k] = r.d[k] * t_mean + r.o[k];
-        g.cov[k] = t_var * dsq[k] + r_var * (1.0f - dsq[k] / mag);
-    }
-    return g;
-}
-
-// 24 encoded features of this lane group (layout: nerf_layout.h).
-__device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[64]) {
-#pragma clang fp contract(off)
-    const float base = __builtin_ldexpf(1.0f, 4 * g - 4);       // 2^(4g-4): scales 4g..4g+3 of -4..11
-    const float half_pi = 1.5707963267948966f;
-#pragma unroll
-    for (int p = 0; p < 12; ++p) {
-        const float scale = base * (float)(1 << (p / 3));
-        const float y = gs.mean[p % 3] * scale;
-        const float yv = gs.cov[p % 3] * (scale * scale);
-        const float damp = expf(-0.5f * yv);
-        act[p] = damp * sinf(y);
-        act[12 + p] = damp * sinf(y + half_pi);
-    }
-}
-
-__device__ __forceinline__ float row_shfl_up(float v, int d) { return __shfl_up(v, d, 16); }
-__device__ __forceinline__ float row_shfl_xor(float v, int d) { return __shfl_xor(v, d, 16); }
-
-__device__ __forceinline__ float row_sum(float v) {
-    v += row_shfl_xor(v, 1);
-    v += row_shfl_xor(v, 2);
-    v += row_shfl_xor(v, 4);
-    v += row_shfl_xor(v, 8);
-    return v;
-}
-__device__ __forceinline__ float row_max(float v) {
-    v = __builtin_fmaxf(v, row_shfl_xor(v, 1));
-    v = __builtin_fmaxf(v, row_shfl_xor(v, 2));
-    v = __builtin_fmaxf(v, row_shfl_xor(v, 4));
-    v = __builtin_fmaxf(v, row_shfl_xor(v, 8));
-    return v;
-}
-
-// Output slot n = 16 T + 4 g + reg of the padded last layer: 0 density, 1..3 color,
-// 4..53 segmentation classes, 54..63 padding (nerf/model.py:591-592).
-__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg) {
-    const int n = 16 * T + 4 * g + reg;
-    return n >= 4 && n < kOut;
-}
-
-// ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+template <bool kTrain>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
@@ -330,24 +132,19 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
     const int64_t my_groups = ka.groups > (int64_t)blockIdx.x
                                   ? (ka.groups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    WeightPipe pipe;
-    pipe.blob = (const char*)a.packed;
-    pipe.ring = smem + kSmallLdsBytes;
-    pipe.to_issue = my_groups * chunks * kNumStages;
-    pipe.issue_stage = 0;
-    pipe.issue_slot = 0;
-    pipe.read_slot = 0;
-    pipe.wave = wave;
-    pipe.lane = lane;
+    FwdPipe pipe;
+    pipe.init(a.packed, smem + kSmallLdsBytes, my_groups * chunks * kNumStages, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
 
     float act[64];
     f32x4 acc[16];
+    float* const ws = a.train_workspace;
 
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
-        int64_t local = grp * kWavesPerWg + wave;
+        const int64_t slot = grp * kWavesPerWg + wave;      // padded ray slot (workspace rows)
+        int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
         const Ray ray = load_ray(a, local);
@@ -364,24 +161,42 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
         for (int c = 0; c < chunks; ++c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = s < P;
+            const int64_t tile = slot * chunks + c;         // chunk index in the workspace
+            const int64_t sp = tile * 16 + j;               // padded sample index
             const float t0 = fencepost(a, local, s);
             const float t1 = fencepost(a, local, s + 1);
             const float t2 = fencepost(a, local, s + 2);
             const Gaussian gs = frustum(ray, t0, t1, a.base_radius_sq);
-            const Gaussian gn = frustum(ray, t1, t2, a.base_radius_sq);
+            float dist;
+            {
+                const Gaussian gn = frustum(ray, t1, t2, a.base_radius_sq);
+                dist = s == P - 1 ? 1e10f : mean_distance(gs, gn);
+            }
             encode(gs, g, act);
+            if (kTrain) {
+                float* hrow = ws + ka.save.h + sp * kEncIn + 4 * g;
+#pragma unroll
+                for (int t = 0; t < kStagesL0; ++t)
+                    *(f32x4*)(hrow + 16 * t) = f32x4{act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]};
+            }
 
             // ---- layer 0: 96 -> 256 ----
             load_bias16(small, g, acc);
             layer_wide<kStagesL0>(pipe, acc, act);
-            layer_norm_relu(small, g, acc, act);
+            layer_norm_relu<kTrain>(small, g, acc, act,
+                                    kTrain ? ws + ka.save.xhat[0] + tile * 4096 + lane * 4 : nullptr,
+                                    kTrain ? ws + ka.save.x[0] + sp * kHidden + 4 * g : nullptr,
+                                    kTrain ? ws + ka.save.rstd[0] + sp : nullptr);
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
             for (int L = 1; L <= 4; ++L) {
                 const float* small_l = small + L * kSmallPerLayer;
                 load_bias16(small_l, g, acc);
                 layer_wide<kStagesHidden>(pipe, acc, act);
-                layer_norm_relu(small_l, g, acc, act);
+                layer_norm_relu<kTrain>(small_l, g, acc, act,
+                                        kTrain ? ws + ka.save.xhat[L] + tile * 4096 + lane * 4 : nullptr,
+                                        kTrain ? ws + ka.save.x[L] + sp * kHidden + 4 * g : nullptr,
+                                        kTrain ? ws + ka.save.rstd[L] + sp : nullptr);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----
             f32x4 out[4];
@@ -391,6 +206,11 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 for (int T = 0; T < 4; ++T) out[T] = b[T];
             }
             layer_out(pipe, out, act);
+            if (kTrain) {
+                float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) *(f32x4*)(otile + T * 256) = out[T];
+            }
 
             // ---- compositing (nerf/model.py:438-469, :660-663) ----
             {
@@ -403,21 +223,13 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                                                    (uint64_t)(a.ray_begin + local), (uint32_t)s, 1u)
                                       * a.density_noise_std;
                 }
-                const float e0 = gn.mean[0] - gs.mean[0], e1 = gn.mean[1] - gs.mean[1],
-                            e2 = gn.mean[2] - gs.mean[2];
-                float dist = __builtin_sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
-                if (s == P - 1) dist = 1e10f;
                 const float alpha = ok ? expf(-__builtin_fmaxf(dens, 0.f) * dist) : 1.0f;
-                float prod = ok ? alpha + 1e-10f : 1.0f;      // inclusive scan over the 16 lanes
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    const float up = row_shfl_up(prod, d);
-                    if (j >= d) prod *= up;
-                }
-                float excl = row_shfl_up(prod, 1);
-                if (j == 0) excl = 1.0f;
-                const float w = ok ? (1.0f - alpha) * (carry * excl) : 0.f;
+                const float prod = row_prefix_prod(ok ? alpha + 1e-10f : 1.0f);
+                const float t_excl = carry * row_shift_up(1.0f, prod);
+                const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
                 carry = carry * __shfl(prod, (lane & 48) | 15);
+                if (kTrain && g == 0)
+                    *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{alpha, t_excl, dist, dens};
 
                 // RGB: valid on lane group 0, harmless elsewhere
                 const float cr = w * (1.0f / (1.0f + expf(-out[0].y)));
@@ -435,16 +247,14 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
-                    m = __builtin_fmaxf(m, xor16(m));
-                    m = __builtin_fmaxf(m, xor32(m));
+                    m = group_max(m);
                     float z = 0.f;
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (is_seg_slot(T, g, r)) z += expf(out[T][r] - m);
-                    z += xor16(z);
-                    z += xor32(z);
+                    z = group_sum(z);
                     const float logz = logf(z);
                     const float lw = logf(w + 1e-10f);
                     // online log-sum-exp over the samples this lane sees
@@ -545,6 +355,22 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int out = 16 * T + row;
             if (out < kOut) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
         }
+    } else if (e >= kBwdBlobOffset) {
+        // transposed image (nerf_layout.h): [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i]
+        const int eb = e - kBwdBlobOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int tin = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int i = lane & 15, g = lane >> 4;
+        if (stage < kStagesL5) {
+            const int out = 16 * stage + 4 * g + r;
+            if (out < kOut) v = pa.p[20][out * kHidden + 16 * tin + i];
+        } else {
+            const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
+            const int tout = (stage - kStagesL5) % kStagesHidden;
+            v = pa.p[4 * L][(16 * tout + 4 * g + r) * kHidden + 16 * tin + i];
+        }
     } else {
         const int i = e - kBlobFloats;
         if (i < 5 * kSmallPerLayer) {
@@ -576,6 +402,14 @@ int nerf_hip_version(void) { return NERF_HIP_ABI_VERSION; }
 const char* nerf_hip_last_error(void) { return nerf_common::last_error(); }
 
 size_t nerf_hip_packed_bytes(void) { return (size_t)kPackedFloats * sizeof(float); }
+
+size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
+    if (n_rays <= 0 || num_samples < 2) return 0;
+    const int chunks = (num_samples - 1 + kSamplesPerWave - 1) / kSamplesPerWave;
+    return (size_t)make_train_layout(n_rays, chunks).total * sizeof(float);
+}
+
+size_t nerf_hip_grad_elements(void) { return (size_t)kGradElements; }
 
 int nerf_hip_pack_weights(const float* const* params, float* packed, void* stream) {
     if (params == nullptr || packed == nullptr)
@@ -612,6 +446,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     ka.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+    ka.save = make_train_layout(a.n_rays, ka.chunks);
+    const bool train = a.train_workspace != nullptr;
 
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
@@ -622,7 +458,12 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     static bool attr_set = false;
     if (!attr_set) {
         rc = nerf_common::check_hip(
-            hipFuncSetAttribute((const void*)nerf_render_fwd_kernel,
+            hipFuncSetAttribute((const void*)nerf_render_fwd_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),
+            "hipFuncSetAttribute");
+        if (rc) return rc;
+        rc = nerf_common::check_hip(
+            hipFuncSetAttribute((const void*)nerf_render_fwd_kernel<true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),
             "hipFuncSetAttribute");
         if (rc) return rc;
@@ -632,7 +473,10 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    hipLaunchKernelGGL(nerf_render_fwd_kernel, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+    if (train)
+        hipLaunchKernelGGL(nerf_render_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+    else
+        hipLaunchKernelGGL(nerf_render_fwd_kernel<false>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

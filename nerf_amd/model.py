@@ -237,22 +237,11 @@ class NeRF(nn.Module):
             self._packed, self._packed_key = packed, key
         return self._packed
 
-    def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
-                ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
-                want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None):
-        lib = _lib.lib()
-        packed = self.packed_parameters()
-        P = num_samples - 1
-        if rgb is None:
-            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
-        if seg is None and want_seg:
-            seg = torch.empty(n_rays, self.segmentation_outputs, dtype=torch.float32, device=device)
-        mean = raw = weights = None
-        if per_sample:
-            mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
-            raw = torch.empty(n_rays, P, 54, dtype=torch.float32, device=device)
-            weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
-        args = _lib.RenderArgs()
+    def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
+                   cameras=None, ray_begin=0, t_values=None, u=None, noise=None,
+                   density_noise_std=0.0, rng_mode=0, rng_state=None, packed=None, rgb=None, seg=None,
+                   mean=None, raw=None, weights=None, train_workspace=None):
+        """Fill a NerfHipRenderArgs block (include/nerf_hip.h) from tensors."""
         args.rays_o, args.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
         if cameras is not None:
             cam_o, cam_r, image_h, image_w, focal = cameras
@@ -265,15 +254,46 @@ class NeRF(nn.Module):
         args.density_noise_std = float(density_noise_std)
         args.rng_mode = int(rng_mode)
         if rng_mode:
-            if rng_state is None:
-                rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_calls)
-                self._philox_calls += 1
             args.rng_seed, args.rng_offset = rng_state
         r_dot = 1.0 / (math.sqrt(3.0) * self.focal_length)          # nerf/model.py:546
         args.base_radius_sq = r_dot ** 2
         args.packed = _lib.ptr(packed)
         args.rgb, args.seg = _lib.ptr(rgb), _lib.ptr(seg)
         args.out_mean, args.out_raw, args.out_weights = _lib.ptr(mean), _lib.ptr(raw), _lib.ptr(weights)
+        args.train_workspace = _lib.ptr(train_workspace)
+
+    def _scratch(self, nbytes, device):
+        """Cached scratch buffer for the backward's partial slabs."""
+        cur = getattr(self, "_scratch_buf", None)
+        if cur is None or cur.numel() * 4 < nbytes or cur.device != device:
+            self._scratch_buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        return self._scratch_buf
+
+    def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
+                ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
+                want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None,
+                train_workspace=None):
+        lib = _lib.lib()
+        packed = self.packed_parameters()
+        P = num_samples - 1
+        if rgb is None:
+            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
+        if seg is None and want_seg:
+            seg = torch.empty(n_rays, self.segmentation_outputs, dtype=torch.float32, device=device)
+        mean = raw = weights = None
+        if per_sample:
+            mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
+            raw = torch.empty(n_rays, P, 54, dtype=torch.float32, device=device)
+            weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
+        if rng_mode and rng_state is None:
+            rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_calls)
+            self._philox_calls += 1
+        args = _lib.RenderArgs()
+        self._fill_args(args, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
+                        cameras=cameras, ray_begin=ray_begin, t_values=t_values, u=u, noise=noise,
+                        density_noise_std=density_noise_std, rng_mode=rng_mode, rng_state=rng_state,
+                        packed=packed, rgb=rgb, seg=seg, mean=mean, raw=raw, weights=weights,
+                        train_workspace=train_workspace)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nerf_hip_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),

@@ -1,0 +1,24 @@
+"""Timing of one training step (fwd + bwd + Adam) on the GPU: BASELINE config 5 batch shape."""
+import sys, time, torch
+sys.path.insert(0, '/root/repo')
+from nerf_amd import NeRF, _lib
+dev = torch.device('cuda:0')
+n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
+torch.manual_seed(0)
+model = NeRF().to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+o = torch.randn(n, 3, device=dev); d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
+def step():
+    rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0)
+    loss = ((rgb - tgt.unsqueeze(1)) ** 2).mean()
+    opt.zero_grad(); loss.backward(); opt.step()
+    return loss
+for _ in range(3): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 10
+for _ in range(K): l = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+print(f"train step {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l):.4f}")
+print(f"  algorithmic {3*601088*n*(S-1)/dt/1e12:.1f} TFLOP/s (fwd+dgrad+wgrad)")

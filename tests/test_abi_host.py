@@ -33,8 +33,11 @@ def test_library_exports_every_declared_symbol(handle):
         assert hasattr(handle, name), name
     assert set(_lib.EXPORTS) == set(names)
     assert handle.nerf_hip_version() == 1
-    # packed image = 74 stages x 16 KiB + 3,904 small floats
-    assert handle.nerf_hip_packed_bytes() == 74 * 16384 + 3904 * 4
+    # packed image = 74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB
+    assert handle.nerf_hip_packed_bytes() == 74 * 16384 + 3904 * 4 + 68 * 16384
+    assert handle.nerf_hip_grad_elements() == 304438
+    assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 4073 * 4
+    assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
 
 
 def test_args_struct_matches_header():
@@ -65,6 +68,9 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     args.n_rays = 0                       # empty batch is a no-op, not an error
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == 0
     assert handle.nerf_hip_pack_weights(None, None, None) == -1
+    assert handle.nerf_hip_render_backward(None, None) == -1
+    bargs = _lib.BackwardArgs()
+    assert handle.nerf_hip_render_backward(ctypes.byref(bargs), None) == -1
 
 
 def test_mirror_keeps_reference_call_surface():

@@ -1,0 +1,142 @@
+"""GPU parity of the HIP backward (training path): parameter
+gradients through NeRF.render_rays against (a) fixture G6 — loss, gradients and one Adam step
+computed by the reference itself — and (b) the oracle's autograd on seeded inputs.
+Tolerance.  Where no ReLU gate sits within rounding of zero the HIP gradients agree with the
+reference to ~3e-7 of each tensor's largest gradient (asserted <= 5e-6 on the x3 fixture).  The
+gradient is discontinuous in those gates, though: a unit whose pre-activation is ~1e-7 flips
+between fp32 evaluations and moves every upstream gradient by O(1e-3) — the reference's own fp32
+gradients differ from its fp64 evaluation by 5e-4 on fixture G6 for exactly this reason.  So the
+bound is 5e-6 + 8 x (largest deviation, over the 22 tensors, of the fp32 reference from the fp64
+oracle): the HIP path must be as close to the reference as the reference is to exact arithmetic
+on that input."""
+import pytest
+import torch
+
+from conftest import golden_params, load_golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+CFG = O.default_config()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make_model(dev, params):
+    from nerf_amd import NeRF
+    model = NeRF()
+    model.load_state_dict(params)
+    return model.to(dev)
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def fp64_gradients(params, loss_fn):
+    p64 = {k: v.double().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    loss_fn(p64).backward()
+    return {k: v.grad.float() for k, v in p64.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("name,scale", [("g6_train_step", 1.0), ("g6_train_step_x3", 3.0)])
+def test_training_step_vs_reference(dev, name, scale):
+    g = load_golden(name)
+    model = make_model(dev, golden_params(scale))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    pixels, _ = model.render_rays(g["rays_o"].to(dev), g["rays_d"].to(dev), 64, randomly_sample=True,
+                                  density_noise_std=float(g["noise_std"]), u=g["u"].to(dev),
+                                  noise=g["noise"].to(dev))
+    assert pixels.requires_grad
+    loss = ((pixels - g["target"].to(dev).unsqueeze(1)) ** 2).mean()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    opt.zero_grad()
+    loss.backward()
+    exact = fp64_gradients(golden_params(scale), lambda p: O.training_loss(
+        p, CFG, g["rays_o"].double(), g["rays_d"].double(), 64, g["target"].double(), g["u"].double(),
+        g["noise"].double(), float(g["noise_std"])))
+    worst = 0.0
+    noise_floor = max(rel_err(g["grad." + k], exact[k]) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        ref = g["grad." + k]
+        assert p.grad is not None and p.grad.shape == ref.shape, k
+        e = rel_err(p.grad.cpu(), ref)
+        worst = max(worst, e)
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+    if scale == 3.0:
+        assert worst <= 5e-6, worst               # no gate near zero on this fixture: exact parity
+    # RGB-only loss: the 50 segmentation rows of the last Linear get exactly zero gradient
+    assert torch.count_nonzero(model.prediction_heads[15].weight.grad[4:]) == 0
+    opt.step()
+    for k, p in model.named_parameters():
+        if "after." + k in g:
+            assert (p.detach().cpu() - g["after." + k]).abs().max() <= 2.1e-4, k
+    print(f"worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("n_rays,num_samples,with_seg", [(5, 9, True), (64, 33, True), (130, 64, False),
+                                                         (256, 100, True)])
+def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
+    torch.manual_seed(100 + n_rays)
+    params = golden_params(2.0)
+    for k in list(params):                              # non-trivial LayerNorm affine and biases
+        if k.startswith("prediction") and params[k].dim() == 1:
+            params[k] = params[k] + 0.2 * torch.randn_like(params[k])
+    o = torch.randn(n_rays, 3)
+    d = torch.randn(n_rays, 3)
+    u = torch.rand(n_rays, num_samples)
+    noise = torch.randn(n_rays, num_samples - 1, 1)
+    w_rgb = torch.randn(n_rays, 3)
+    w_seg = torch.randn(n_rays, 50) * 0.05
+
+    ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    rgb_r, seg_r = O.render_rays(ref, CFG, o, d, num_samples, u=u, noise=noise, density_noise_std=0.5)
+    loss_r = (rgb_r * w_rgb).sum() + ((seg_r * w_seg).sum() if with_seg else 0.0)
+    loss_r.backward()
+
+    model = make_model(dev, params)
+    rgb, seg = model.render_rays(o.to(dev), d.to(dev), num_samples, randomly_sample=True,
+                                 density_noise_std=0.5, u=u.to(dev), noise=noise.to(dev))
+    loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + ((seg[:, 0] * w_seg.to(dev)).sum() if with_seg else 0.0)
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
+    def loss64(p):
+        a, b = O.render_rays(p, CFG, o.double(), d.double(), num_samples, u=u.double(),
+                             noise=noise.double(), density_noise_std=0.5)
+        return (a * w_rgb.double()).sum() + ((b * w_seg.double()).sum() if with_seg else 0.0)
+    exact = fp64_gradients(params, loss64)
+    noise_floor = max(rel_err(ref[k].grad, exact[k]) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad.cpu(), ref[k].grad)
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+
+
+def test_backward_is_deterministic_and_accumulates(dev):
+    torch.manual_seed(1)
+    model = make_model(dev, golden_params(3.0))
+    o, d = torch.randn(100, 3).to(dev), torch.randn(100, 3).to(dev)
+    grads = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        rgb, _ = model.render_rays(o, d, 64)
+        (rgb ** 2).sum().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+    assert torch.equal(grads[0], grads[1])               # no atomics: bitwise reproducible
+    rgb, _ = model.render_rays(o, d, 64)                 # second backward accumulates into .grad
+    (rgb ** 2).sum().backward()
+    acc = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.allclose(acc, 2 * grads[0], rtol=1e-6, atol=0)
+    assert model.last_flat_grad.numel() == 304438
+
+
+def test_no_grad_path_skips_the_workspace(dev):
+    model = make_model(dev, golden_params(1.0))
+    o, d = torch.randn(8, 3).to(dev), torch.randn(8, 3).to(dev)
+    with torch.no_grad():
+        rgb, _ = model.render_rays(o, d, 16)
+    assert not rgb.requires_grad
+    rgb2, _ = model.render_rays(o, d, 16)
+    assert rgb2.requires_grad and torch.equal(rgb, rgb2.detach())
