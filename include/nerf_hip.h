@@ -126,6 +126,30 @@ typedef struct NerfHipBackwardArgs {
 size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples);
 int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream);
 
+/* Batched replacement of PixelRayDataset.__getitem__ + default_collate (nerf/dataset.py:246-316,
+ * train_conditional_nerf.py:100-101): decode flat example ids (w = id % W, h = (id / W) % H,
+ * image = (id / (W*H)) % B, dataset.py:283-291), gather the pixel / label, build the camera-frame
+ * ray of that pixel (nerf/model.py:271-278) and rotate it by the pose (model.py:367). */
+typedef struct NerfHipGatherArgs {
+    const int64_t* index;       /* [n] example ids                                        */
+    int64_t n;
+    const float* images;        /* [B,H,W,3]                                              */
+    const int64_t* segmentation;/* [B,H,W] or NULL                                        */
+    const float* poses;         /* [B,4,4] homogeneous camera-to-world                    */
+    int32_t batch, image_h, image_w;
+    float focal_length;
+    float* pixels;              /* [n,3]                                                  */
+    int64_t* label;             /* [n] or NULL                                            */
+    float* rays;                /* [n,3] camera-frame ray                                 */
+    float* rays_o;              /* [n,3] = pose[:3,3]                                     */
+    float* rays_d;              /* [n,3] = pose[:3,:3] . ray                              */
+    int64_t* image_wi;          /* [n] decoded column / row / image ids (any may be NULL) */
+    int64_t* image_hi;
+    int64_t* image_bi;
+} NerfHipGatherArgs;
+
+int nerf_hip_gather_pixel_rays(const NerfHipGatherArgs* args, void* stream);
+
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
  * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */

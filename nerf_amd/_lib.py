@@ -41,6 +41,15 @@ class BackwardArgs(ctypes.Structure):
                 ("scratch", _f32p)]
 
 
+class GatherArgs(ctypes.Structure):
+    """Mirror of NerfHipGatherArgs (include/nerf_hip.h)."""
+    _fields_ = [("index", _f32p), ("n", ctypes.c_int64), ("images", _f32p), ("segmentation", _f32p),
+                ("poses", _f32p), ("batch", ctypes.c_int32), ("image_h", ctypes.c_int32),
+                ("image_w", ctypes.c_int32), ("focal_length", ctypes.c_float),
+                ("pixels", _f32p), ("label", _f32p), ("rays", _f32p), ("rays_o", _f32p),
+                ("rays_d", _f32p), ("image_wi", _f32p), ("image_hi", _f32p), ("image_bi", _f32p)]
+
+
 _lib = None
 
 
@@ -69,6 +78,8 @@ def lib():
     handle.nerf_hip_backward_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
     handle.nerf_hip_render_backward.restype = ctypes.c_int
     handle.nerf_hip_render_backward.argtypes = [ctypes.POINTER(BackwardArgs), ctypes.c_void_p]
+    handle.nerf_hip_gather_pixel_rays.restype = ctypes.c_int
+    handle.nerf_hip_gather_pixel_rays.argtypes = [ctypes.POINTER(GatherArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -83,7 +94,7 @@ def lib():
 EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_packed_bytes",
            "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
            "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
-           "nerf_hip_timing", "nerf_hip_timing_read")
+           "nerf_hip_gather_pixel_rays", "nerf_hip_timing", "nerf_hip_timing_read")
 
 
 def check(rc, what):

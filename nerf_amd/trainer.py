@@ -1,0 +1,150 @@
+"""Training / evaluation loop of the reference script (train_conditional_nerf.py:106-174) on the
+generation-C call surface, single GPU or data-parallel (one process per GPU, RCCL all-reduce of
+the flat gradient).  Same recipe: Adam, MSE of ``render_rays`` pixels against the sampled pixels
+(``.unsqueeze(1)`` target, :132), last view held out (:89-95), evaluation by ``render_image``
+every ``log_interval`` iterations with PSNR = -10 ln(mse) / 2.30258509299 (:152-153), and the
+same files: ``params.json``, ``model.pth``, ``psnrs.npy``, ``iternums.npy``,
+``rendered_images.npy``, ``ground_truth_images.npy`` (:53-69, :160-174).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .dataset import PixelRayDataset
+from .model import NeRF
+from . import parallel
+
+
+def psnr(rendered, target):
+    """train_conditional_nerf.py:152-153 (natural log over a hard-coded ln 10)."""
+    return -10.0 * torch.log(((rendered - target) ** 2).mean()) / 2.30258509299
+
+
+def synthetic_scene(num_views=12, size=32, focal=None, num_samples=48, device="cuda", seed=0,
+                    weight_scale=3.0, radius=4.0):
+    """A self-consistent scene when no dataset is on disk (tiny_nerf_data.npz is not shipped):
+    views of a 'teacher' field (default init, Linear weights x ``weight_scale``) rendered by the
+    renderer itself from poses on a sphere.  Returns images [V,H,W,3], poses [V,4,4], focal."""
+    focal = float(focal if focal is not None else size * 1.12)
+    gen = torch.Generator().manual_seed(seed)
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    teacher = NeRF(focal_length=focal)
+    torch.set_rng_state(state)
+    with torch.no_grad():
+        for slot in (0, 3, 6, 9, 12, 15):
+            teacher.prediction_heads[slot].weight.mul_(weight_scale)
+    teacher = teacher.to(device)
+    yaw = torch.rand(num_views, generator=gen) * 2 * np.pi
+    elev = 0.3 + 0.5 * torch.rand(num_views, generator=gen)
+    pos = NeRF.spherical_to_cartesian(yaw, elev) * radius
+    eye = -pos / pos.norm(dim=-1, keepdim=True)
+    z = torch.tensor([[0.0, 0.0, 1.0]]).expand_as(eye)
+    up = z - (z * eye).sum(-1, keepdim=True) * eye
+    up = up / up.norm(dim=-1, keepdim=True)
+    rot = torch.stack([torch.linalg.cross(eye, up, dim=-1), up, -eye], dim=-1)
+    poses = torch.eye(4).repeat(num_views, 1, 1)
+    poses[:, :3, :3], poses[:, :3, 3] = rot, pos
+    poses = poses.to(device)
+    with torch.no_grad():
+        images, _ = teacher.render_image(poses[:, :3, 3].contiguous(), poses[:, :3, :3].contiguous(),
+                                         size, size, focal, num_samples)
+    return images, poses, focal
+
+
+def load_scene(path, device):
+    """``.npz`` in the tiny_nerf layout (images [V,H,W,3], poses [V,4,4], focal)."""
+    with np.load(path) as z:
+        images = torch.from_numpy(z["images"].astype(np.float32)).to(device)
+        poses = torch.from_numpy(z["poses"].astype(np.float32)).to(device)
+        focal = float(z["focal"])
+    return images, poses, focal
+
+
+class Trainer:
+    def __init__(self, images, poses, focal_length, logging_dir=None, batch_size=1024,
+                 learning_rate=1e-4, num_samples_per_ray=64, density_noise_std=1.0, log_interval=1000,
+                 segmentation=None, model=None, seed=0, rng="torch"):
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.world = dist.get_world_size() if self.distributed else 1
+        device = images.device
+        self.image_h, self.image_w = images.shape[1], images.shape[2]
+        self.focal_length = focal_length
+        # hold out the last view (train_conditional_nerf.py:89-95)
+        self.test_image, self.test_pose = images[-1:], poses[-1:]
+        if segmentation is None:
+            segmentation = torch.zeros(images.shape[:3], dtype=torch.int64, device=device)
+        self.dataset = PixelRayDataset(images[:-1], segmentation[:-1], poses[:-1], focal_length)
+        if model is None:
+            torch.manual_seed(seed)
+            model = NeRF(focal_length=focal_length).to(device)
+        self.model = model
+        self.model.rng = rng
+        if self.distributed:
+            parallel.broadcast_parameters(self.model)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate)
+        self.reduce = parallel.FlatGradientAllReduce(self.model.parameters())
+        self.batch_size = batch_size
+        self.num_samples = num_samples_per_ray
+        self.density_noise_std = density_noise_std
+        self.log_interval = log_interval
+        self.logging_dir = logging_dir
+        self.sampler = torch.Generator(device=device).manual_seed(seed)     # same order on all ranks
+        self.psnrs, self.iternums, self.rendered, self.truth = [], [], [], []
+        self.iteration = -1
+        if logging_dir is not None and self.rank == 0:
+            os.makedirs(logging_dir, exist_ok=True)
+
+    def write_params(self, params):
+        if self.logging_dir is not None and self.rank == 0:
+            with open(os.path.join(self.logging_dir, "params.json"), "w") as f:
+                json.dump(params, f, indent=4)
+
+    def train_step(self, batch):
+        pixels, _ = self.model.render_rays(batch["rays_o"], batch["rays_d"], self.num_samples,
+                                           randomly_sample=True,
+                                           density_noise_std=self.density_noise_std)
+        self.optimizer.zero_grad(set_to_none=False)
+        loss = ((pixels - batch["pixels"].unsqueeze(1)) ** 2).mean()
+        loss.backward()
+        if self.distributed:
+            self.reduce()
+        self.optimizer.step()
+        return loss.detach()
+
+    def evaluate(self):
+        with torch.no_grad():
+            render, _ = self.model.render_image(self.test_pose[..., :3, 3].contiguous(),
+                                                self.test_pose[..., :3, :3].contiguous(),
+                                                self.image_h, self.image_w, self.focal_length,
+                                                self.num_samples)
+        value = psnr(render, self.test_image)
+        self.psnrs.append(value.cpu().numpy())
+        self.iternums.append(self.iteration)
+        self.rendered.append(render.cpu().numpy())
+        self.truth.append(self.test_image.cpu().numpy())
+        if self.logging_dir is not None and self.rank == 0:
+            d = self.logging_dir
+            torch.save(self.model.state_dict(), os.path.join(d, "model.pth"))
+            np.save(os.path.join(d, "psnrs.npy"), np.asarray(self.psnrs))
+            np.save(os.path.join(d, "iternums.npy"), np.asarray(self.iternums))
+            np.save(os.path.join(d, "rendered_images.npy"), np.asarray(self.rendered))
+            np.save(os.path.join(d, "ground_truth_images.npy"), np.asarray(self.truth))
+        return float(value)
+
+    def fit(self, epochs=1, max_iterations=None):
+        last = None
+        for _ in range(epochs):
+            for batch in self.dataset.batches(self.batch_size, shuffle=True, generator=self.sampler,
+                                              rank=self.rank, world_size=self.world):
+                self.iteration += 1
+                last = self.train_step(batch)
+                if self.iteration % self.log_interval == 0:
+                    self.evaluate()
+                if max_iterations is not None and self.iteration + 1 >= max_iterations:
+                    return last
+        return last

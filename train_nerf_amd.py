@@ -1,0 +1,54 @@
+"""Training entry point with the reference script's flags (train_conditional_nerf.py:20-49) on
+the generation-C renderer.  Single GPU: ``python train_nerf_amd.py --data scene.npz``; data
+parallel: ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1
+train_nerf_amd.py ...`` (one process per GPU, RCCL all-reduce of the 1.2 MB gradient per step).
+``--data synthetic`` trains against views of a synthetic teacher field (the tiny_nerf Lego file
+of the reference's notebook is not redistributable here)."""
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+from nerf_amd import trainer as T
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser("Train a NeRF model with the MI355X renderer")
+    ap.add_argument("--logging-dir", type=str, default="./")
+    ap.add_argument("--data", type=str, default="synthetic")
+    ap.add_argument("--epochs", type=int, default=30)
+    ap.add_argument("--camera-focal-length", type=float, default=35.0)
+    ap.add_argument("--camera-ccd-width", type=float, default=32.0)
+    ap.add_argument("--batch-size", type=int, default=4096)
+    ap.add_argument("--normalize-position", type=float, default=16.0)      # accepted, unused (gen. B)
+    ap.add_argument("--learning-rate", type=float, default=0.0001)
+    ap.add_argument("--near-plane", type=float, default=0.0)               # accepted, unused (gen. B)
+    ap.add_argument("--far-plane", type=float, default=20.0)               # accepted, unused (gen. B)
+    ap.add_argument("--num-samples-per-ray", type=int, default=64)
+    ap.add_argument("--density-noise-std", type=float, default=1.0)
+    ap.add_argument("--log-interval", type=int, default=1000)
+    ap.add_argument("--max-iterations", type=int, default=None)
+    ap.add_argument("--rng", choices=("torch", "philox"), default="philox")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    if args.data == "synthetic":
+        images, poses, focal = T.synthetic_scene(device=device)
+    else:
+        images, poses, focal = T.load_scene(args.data, device)
+    run = T.Trainer(images, poses, focal, logging_dir=args.logging_dir, batch_size=args.batch_size,
+                    learning_rate=args.learning_rate, num_samples_per_ray=args.num_samples_per_ray,
+                    density_noise_std=args.density_noise_std, log_interval=args.log_interval,
+                    rng=args.rng)
+    run.write_params(vars(args))
+    run.fit(epochs=args.epochs, max_iterations=args.max_iterations)
+    if run.rank == 0 and run.psnrs:
+        print(f"iteration {run.iternums[-1]}: held-out PSNR {float(run.psnrs[-1]):.2f} dB")
+    if world > 1:
+        dist.destroy_process_group()
