@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnerf_hip.so")
+# NERF_HIP_LIB selects another build of the same ABI (kernel experiments: scripts/ablate.py)
+LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
 ABI_VERSION = 1
 NUM_PARAM_TENSORS = 22
 

@@ -24,16 +24,20 @@ def up_to_date():
     return os.path.getmtime(OUT) >= newest
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
+def build(force=False, verbose=False, out=None, defines=()):
+    """Compile every .hip under csrc/ into one shared library.  ``out``/``defines`` build an
+    experimental variant next to the product library (scripts/ablate.py)."""
+    if out is None and not force and up_to_date():
         return OUT
+    out = out or OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC, "-Wno-unused-value", "-o", OUT] + sources()
+           "-I", INCLUDE, "-I", CSRC, "-Wno-unused-value", "-o", out]
+    cmd += [f"-D{d}" for d in defines] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

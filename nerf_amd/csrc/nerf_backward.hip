@@ -135,11 +135,8 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     }
     const float* small = (const float*)smem;
 
-    const int64_t my_groups = ba.groups > (int64_t)blockIdx.x
-                                  ? (ba.groups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     BwdPipe pipe;
-    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, my_groups * chunks * kBwdStages, wave,
-              lane);
+    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();
@@ -264,12 +261,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < kStagesL5; ++t) {
-                const f32x4* st = pipe.begin_stage();
-                turn(t);                          // layer-0 partials of the previous chunk
-                stage_wide(st, acc, dout[t].x, dout[t].y, dout[t].z, dout[t].w);
-            }
+            layer_wide_v4<kStagesL5>(pipe, acc, dout, turn);   // hook: layer-0 partials of the previous chunk
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {

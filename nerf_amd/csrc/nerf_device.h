@@ -65,34 +65,34 @@ template <int kStagesInImage>
 struct WeightPipe {
     const char* blob;           // packed image, stage 0
     char* ring;                 // LDS ring base
-    int64_t to_issue;           // stages still to be issued by this workgroup
     int issue_stage;            // next stage of the image to issue (cyclic)
     int issue_slot;             // ring slot it goes to
     int read_slot;              // ring slot of the stage being consumed
     int wave;                   // wave id in the workgroup (uniform)
     int lane;
 
-    __device__ __forceinline__ void init(const void* image, char* lds_ring, int64_t stages, int w,
-                                         int l) {
+    __device__ __forceinline__ void init(const void* image, char* lds_ring, int w, int l) {
         blob = (const char*)image;
         ring = lds_ring;
-        to_issue = stages;
         issue_stage = issue_slot = read_slot = 0;
         wave = w;
         lane = l;
     }
 
+    // Unconditional: past the last stage a workgroup needs, the (cyclic) image is simply fetched
+    // again into slots nobody reads — two wasted 16 KiB DMAs per workgroup at kernel end buy a
+    // branch-free stage loop.  The kernel drains vmcnt before it exits.
     __device__ __forceinline__ void issue() {
-        if (to_issue > 0) {
-            const char* src = blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16;
-            char* dst = ring + issue_slot * kStageBytes + wave * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + i * 1024),
-                    (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-            }
-            --to_issue;
+        {
+            // one address + one M0 base, the four 1 KiB pieces by the instruction's immediate
+            // offset (it applies to the global and the LDS address alike)
+            const auto* src = (const __attribute__((address_space(1))) char*)(
+                blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16);
+            auto* dst = (__attribute__((address_space(3))) char*)(ring + issue_slot * kStageBytes + wave * 4096);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
         }
         issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;
         issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
@@ -100,16 +100,28 @@ struct WeightPipe {
 
     // Top of a stage: this wave's DMA pieces of the stage have landed (the 4 youngest = the next
     // stage may still fly; any other younger vector-memory op only makes the wait conservative),
-    // every wave has passed the barrier, so (a) all 16 pieces are visible and (b) nobody still
-    // reads the slot the next issue overwrites.
-    __device__ __forceinline__ const f32x4* begin_stage() {
+    // every wave has passed the barrier, so (a) all 16 pieces are visible and (b) every wave has
+    // issued its last reads of the slot the next issue() overwrites (an LDS-DMA write lands a
+    // global-memory round trip after its issue, long after those already-queued LDS reads).
+    // The caller reads its first operands, THEN calls issue(): the reads' latency hides under the
+    // previous stage's trailing MFMAs instead of behind the DMA address arithmetic.
+    __device__ __forceinline__ const f32x4* open_stage() {
+#ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
+#ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        issue();
         const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
         read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
         return p;
+    }
+    __device__ __forceinline__ void prefetch_next() {
+        asm volatile("" ::: "memory");
+#ifndef NERF_EXP_NODMA
+        issue();
+#endif
     }
 };
 
@@ -117,38 +129,77 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// One 16 KiB stage against 16 output tiles: k-group values b0..b3 (this lane's B operands).
-__device__ __forceinline__ void stage_wide(const f32x4* st, f32x4 (&acc)[16], float b0, float b1,
-                                           float b2, float b3) {
-#pragma unroll
-    for (int tp = 0; tp < 8; ++tp) {
-        const f32x4 a0 = st[(2 * tp) * 64];
-        const f32x4 a1 = st[(2 * tp + 1) * 64];
-        acc[2 * tp] = mfma4(a0.x, b0, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.x, b0, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.y, b1, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.y, b1, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.z, b2, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.z, b2, acc[2 * tp + 1]);
-        acc[2 * tp] = mfma4(a0.w, b3, acc[2 * tp]);
-        acc[2 * tp + 1] = mfma4(a1.w, b3, acc[2 * tp + 1]);
-    }
-}
-
 struct NoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
-// hook(t) runs right after the barrier that opens stage t (every wave has passed it)
+// A 16-out-tile layer of KT stages (k-groups), one 16 KiB stage each: stage t holds, for every
+// out tile T, the four A operands of k-group t; B operands are act[4 t .. 4 t + 3].
+//
+// Software pipeline over "groups" of two out tiles (8 MFMAs, 256 cycles): the two ds_read_b128 of
+// group G+1 are issued right after the first MFMA of group G — i.e. right after the wait that
+// retired group G's own reads — so every LDS read has a full group to land and the only
+// lgkmcnt(0) in the loop never sees a freshly issued read.  When group G+1 opens a new stage, the
+// stage hand-over (vmcnt wait, barrier, DMA issue for stage +2) happens at that same point, with
+// 7 MFMAs of the old stage still to issue behind it.  At that barrier this wave has completed all
+// its reads of the finished stage (they were retired by the wait above), so the DMA that is issued
+// next may overwrite that ring slot: write-after-read safe by construction.
+// hook(t) runs once per stage, after the stage's barrier.
 template <int KT, class Pipe, class Hook = NoHook>
 __device__ __forceinline__ void layer_wide(Pipe& pipe, f32x4 (&acc)[16], const float (&act)[64],
                                            Hook hook = Hook()) {
+    f32x4 a[2][2];
+    const f32x4* st = pipe.open_stage();
+    a[0][0] = st[0];
+    a[0][1] = st[64];
+    pipe.prefetch_next();
+    hook(0);
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const f32x4* st = pipe.begin_stage();
-        hook(t);
-        stage_wide(st, acc, act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]);
+        const float b0 = act[4 * t], b1 = act[4 * t + 1], b2 = act[4 * t + 2], b3 = act[4 * t + 3];
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+            const int cur = tp & 1, nxt = cur ^ 1;          // 8 groups per stage: parity carries over
+            const f32x4 a0 = a[cur][0], a1 = a[cur][1];
+            acc[2 * tp] = mfma4(a0.x, b0, acc[2 * tp]);
+            __builtin_amdgcn_sched_barrier(0);   // the wait for this group's operands is above this line
+            if (tp < 7) {
+                a[nxt][0] = st[(2 * tp + 2) * 64];
+                a[nxt][1] = st[(2 * tp + 3) * 64];
+            } else if (t + 1 < KT) {
+                st = pipe.open_stage();
+                a[nxt][0] = st[0];
+                a[nxt][1] = st[64];
+                pipe.prefetch_next();
+                hook(t + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // reads stay HERE (the scheduler would sink them)
+            acc[2 * tp + 1] = mfma4(a1.x, b0, acc[2 * tp + 1]);
+            acc[2 * tp] = mfma4(a0.y, b1, acc[2 * tp]);
+            acc[2 * tp + 1] = mfma4(a1.y, b1, acc[2 * tp + 1]);
+            acc[2 * tp] = mfma4(a0.z, b2, acc[2 * tp]);
+            acc[2 * tp + 1] = mfma4(a1.z, b2, acc[2 * tp + 1]);
+            acc[2 * tp] = mfma4(a0.w, b3, acc[2 * tp]);
+            acc[2 * tp + 1] = mfma4(a1.w, b3, acc[2 * tp + 1]);
+            // keep groups apart: merged groups would re-issue the reads just before their use
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+}
+
+// Same for a short run of stages whose B operands are f32x4 values (backward, layer 5).
+template <int KT, class Pipe, class Hook = NoHook>
+__device__ __forceinline__ void layer_wide_v4(Pipe& pipe, f32x4 (&acc)[16], const f32x4 (&bv)[KT],
+                                              Hook hook = Hook()) {
+    float act[64];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        act[4 * t] = bv[t].x;
+        act[4 * t + 1] = bv[t].y;
+        act[4 * t + 2] = bv[t].z;
+        act[4 * t + 3] = bv[t].w;
+    }
+    layer_wide<KT>(pipe, acc, act, hook);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,9 +360,15 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         const float scale = base * (float)(1 << (p / 3));
         const float y = gs.mean[p % 3] * scale;
         const float yv = gs.cov[p % 3] * (scale * scale);
+#ifdef NERF_ABL_ENCODE      /* timing experiment only: no transcendental */
+        const float damp = 1.0f - 0.001f * yv;
+        act[p] = damp * (y * 1e-6f);
+        act[12 + p] = damp * ((y + half_pi) * 1e-6f);
+#else
         const float damp = expf(-0.5f * yv);
         act[p] = damp * sinf(y);
         act[12 + p] = damp * sinf(y + half_pi);
+#endif
     }
 }
 

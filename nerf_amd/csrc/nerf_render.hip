@@ -31,14 +31,20 @@ typedef WeightPipe<kNumStages> FwdPipe;
 __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&acc)[4], const float (&act)[64]) {
 #pragma unroll
     for (int s = 0; s < kStagesL5; ++s) {
-        const f32x4* st = pipe.begin_stage();
+        const f32x4* st = pipe.open_stage();
+        f32x4 q[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = st[i * 64];
+        pipe.prefetch_next();
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
             const int t = 4 * s + tl;
-            const f32x4 a0 = st[(4 * tl + 0) * 64];
-            const f32x4 a1 = st[(4 * tl + 1) * 64];
-            const f32x4 a2 = st[(4 * tl + 2) * 64];
-            const f32x4 a3 = st[(4 * tl + 3) * 64];
+            if (tl + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[((tl + 1) & 1) * 4 + i] = st[(4 * (tl + 1) + i) * 64];
+            }
+            const f32x4 a0 = q[(tl & 1) * 4 + 0], a1 = q[(tl & 1) * 4 + 1], a2 = q[(tl & 1) * 4 + 2],
+                        a3 = q[(tl & 1) * 4 + 3];
             acc[0] = mfma4(a0.x, act[4 * t], acc[0]);
             acc[1] = mfma4(a1.x, act[4 * t], acc[1]);
             acc[2] = mfma4(a2.x, act[4 * t], acc[2]);
@@ -67,6 +73,13 @@ template <bool kTrain>
 __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, const f32x4 (&acc)[16],
                                                 float (&act)[64], float* save_xhat_tile,
                                                 float* save_x_row, float* save_rstd) {
+#ifdef NERF_ABL_LN           /* timing experiment only: ReLU without the normalisation */
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
+    return;
+#endif
     float s = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
@@ -130,13 +143,20 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     }
     const float* small = (const float*)smem;
 
-    const int64_t my_groups = ka.groups > (int64_t)blockIdx.x
-                                  ? (ka.groups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     FwdPipe pipe;
-    pipe.init(a.packed, smem + kSmallLdsBytes, my_groups * chunks * kNumStages, wave, lane);
+    pipe.init(a.packed, smem + kSmallLdsBytes, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
+#ifdef NERF_STAGGER
+    // The two workgroups of a CU run the same program; started together they stay in phase and
+    // their VALU phases (encoding, LayerNorm, compositing) coincide instead of hiding under the
+    // partner's MFMAs.  Delay the second half of the grid (the second resident block per CU under
+    // round-robin dispatch) by about half a chunk, once.
+    if (blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < NERF_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     float act[64];
     f32x4 acc[16];
@@ -151,12 +171,9 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
         float carry = 1.0f;                     // prod (alpha_i + 1e-10) over finished chunks
         float rgb0 = 0.f, rgb1 = 0.f, rgb2 = 0.f;
-        float segM[16], segS[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            segM[i] = -__builtin_inff();
-            segS[i] = 0.f;
-        }
+        // running log-sum-exp over the ray's samples of ONE output slot per lane: lane (j, g)
+        // owns slot i = j of its lane group, i.e. output n = 16 (j >> 2) + 4 g + (j & 3)
+        float seg_m = -__builtin_inff(), seg_s = 0.f;
 
         for (int c = 0; c < chunks; ++c) {
             const int s = c * kSamplesPerWave + j;
@@ -239,7 +256,11 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 rgb1 += row_sum(cg);
                 rgb2 += row_sum(cb);
 
+#ifdef NERF_ABL_COMP         /* timing experiment only: no segmentation compositing */
+                if (false) {
+#else
                 if (a.seg != nullptr) {
+#endif
                     // log_softmax over the 50 class logits of this sample
                     float m = -__builtin_inff();
 #pragma unroll
@@ -257,19 +278,24 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                     z = group_sum(z);
                     const float logz = logf(z);
                     const float lw = logf(w + 1e-10f);
-                    // online log-sum-exp over the samples this lane sees
+                    // log-sum-exp over the 16 samples of the chunk per slot (row reductions), then
+                    // merged into the owning lane's running (max, sum)
+                    float cm = 0.f, cs = 0.f;
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int i = 4 * T + r;
-                            const float v = lw + ((out[T][r] - m) - logz);
-                            if (ok) {
-                                const float nm = __builtin_fmaxf(segM[i], v);
-                                segS[i] = segS[i] * expf(segM[i] - nm) + expf(v - nm);
-                                segM[i] = nm;
+                            const float v = ok ? lw + ((out[T][r] - m) - logz) : -__builtin_inff();
+                            const float vm = row_max(v);              // lane 0 of a chunk is always valid
+                            const float ve = row_sum(expf(v - vm));
+                            if (j == 4 * T + r) {
+                                cm = vm;
+                                cs = ve;
                             }
                         }
+                    const float nm = __builtin_fmaxf(seg_m, cm);
+                    seg_s = seg_s * expf(seg_m - nm) + cs * expf(cm - nm);
+                    seg_m = nm;
                 }
 
                 // optional per-sample outputs (NeRF.forward, nerf/model.py:553-594)
@@ -302,20 +328,8 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             a.rgb[local * 3 + lane] = v;
         }
         if (a.seg != nullptr) {
-            // after the row reductions every lane of a row holds the same 16 values; lane (j, g)
-            // keeps slot i = j, i.e. output n = 16 (j >> 2) + 4 g + (j & 3), so the wave's 64 lanes
-            // cover n = 0..63 once and the 50 class values leave in one store instruction.
-            float mine = 0.f;
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 4 * T + r;
-                    const float mx = row_max(segM[i]);
-                    const float sm = row_sum(segS[i] * expf(segM[i] - mx));
-                    const float val = mx + logf(sm);
-                    if (j == i) mine = val;
-                }
+            // the wave's 64 lanes cover n = 0..63 once: the 50 class values leave in one store
+            const float mine = seg_m + logf(seg_s);
             const int n = 16 * (j >> 2) + 4 * g + (j & 3);
             if (ray_ok && n >= 4 && n < kOut) a.seg[local * kSegClasses + (n - 4)] = mine;
         }
