@@ -350,6 +350,28 @@ __device__ __forceinline__ Gaussian frustum(const Ray& r, float t0, float t1, fl
     return g;
 }
 
+// sin(y) for |y| up to ~2e5 rad (the encoding's largest scale times the far plane) to ~1 ulp:
+// half-turn reduction in fp64 (n = rint(y / pi), r = y - n pi: the product is exact to 2e-11 at
+// these magnitudes), then an odd degree-11 minimax polynomial on [-pi/2, pi/2] (3e-11 fit error,
+// evaluated as r + r^3 s(r^2) so the leading term is exact) and the (-1)^n sign.  ~20 issue slots
+// against ~100+ for the general-purpose sinf with its Payne-Hanek path.
+__device__ __forceinline__ float sin_reduced(float y) {
+    const double yd = (double)y;
+    const double n = __builtin_rint(yd * 0.31830988618379067);
+    const float r = (float)__builtin_fma(-n, 3.1415926535897931, yd);
+    const float u = r * r;
+    float s = __builtin_fmaf(u, -2.3794713703943473e-08f, 2.7518855647935822e-06f);
+    s = __builtin_fmaf(u, s, -0.00019840702862741812f);
+    s = __builtin_fmaf(u, s, 0.008333329264456273f);
+    s = __builtin_fmaf(u, s, -0.16666666541439012f);
+    const float p = __builtin_fmaf(r * u, s, r);
+    return ((int)n & 1) ? -p : p;
+}
+
+// exp for log-domain bookkeeping where ~2e-6 relative error is immaterial (segmentation
+// log-probabilities, asserted to 1e-4): v_exp_f32 on x * log2(e)
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // 24 encoded features of this lane group (layout: nerf_layout.h).
 __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[64]) {
 #pragma clang fp contract(off)
@@ -366,8 +388,8 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         act[12 + p] = damp * ((y + half_pi) * 1e-6f);
 #else
         const float damp = expf(-0.5f * yv);
-        act[p] = damp * sinf(y);
-        act[12 + p] = damp * sinf(y + half_pi);
+        act[p] = damp * sin_reduced(y);
+        act[12 + p] = damp * sin_reduced(y + half_pi);
 #endif
     }
 }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) z += expf(out[T][r] - m);
+                            if (is_seg_slot(T, g, r)) z += exp_fast(out[T][r] - m);
                     z = group_sum(z);
                     const float logz = logf(z);
                     const float lw = logf(w + 1e-10f);
@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                         for (int r = 0; r < 4; ++r) {
                             const float v = ok ? lw + ((out[T][r] - m) - logz) : -__builtin_inff();
                             const float vm = row_max(v);              // lane 0 of a chunk is always valid
-                            const float ve = row_sum(expf(v - vm));
+                            const float ve = row_sum(exp_fast(v - vm));
                             if (j == 4 * T + r) {
                                 cm = vm;
                                 cs = ve;
                             }
                         }
                     const float nm = __builtin_fmaxf(seg_m, cm);
-                    seg_s = seg_s * expf(seg_m - nm) + cs * expf(cm - nm);
+                    seg_s = seg_s * exp_fast(seg_m - nm) + cs * exp_fast(cm - nm);
                     seg_m = nm;
                 }
 
