@@ -150,6 +150,24 @@ typedef struct NerfHipGatherArgs {
 
 int nerf_hip_gather_pixel_rays(const NerfHipGatherArgs* args, void* stream);
 
+/* Hierarchical sampling (BASELINE config 3).  The reference only carries vestigial docstrings for
+ * it (nerf/model.py:191-193, :642-645), so this follows Mildenhall et al. 2020, section 5.2:
+ * the coarse pass's compositing weights define a piecewise-constant PDF over the coarse intervals,
+ * `num_fine` new fenceposts are drawn by inverse-transform sampling, and the fine pass evaluates
+ * the sorted union of coarse and fine fenceposts.  PARITY UNPINNED: oracle/ holds the spec. */
+typedef struct NerfHipResampleArgs {
+    int64_t n_rays;
+    int32_t num_coarse;         /* S_c coarse fenceposts per ray (2 <= S_c <= 1024)        */
+    int32_t num_fine;           /* S_f fenceposts to draw (1 <= S_f <= 1024)               */
+    const float* t_coarse;      /* [n_rays,S_c] coarse fenceposts, ascending               */
+    const float* weights;       /* [n_rays,S_c-1] coarse compositing weights               */
+    const float* u;             /* [n_rays,S_f] sorted uniforms, or NULL: (k + 0.5) / S_f  */
+    float pdf_floor;            /* added to every weight (1e-5 in the paper's code)        */
+    float* t_union;             /* [n_rays,S_c+S_f] sorted union, output                   */
+} NerfHipResampleArgs;
+
+int nerf_hip_resample_pdf(const NerfHipResampleArgs* args, void* stream);
+
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
  * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */

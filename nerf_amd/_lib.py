@@ -51,6 +51,13 @@ class GatherArgs(ctypes.Structure):
                 ("rays_d", _f32p), ("image_wi", _f32p), ("image_hi", _f32p), ("image_bi", _f32p)]
 
 
+class ResampleArgs(ctypes.Structure):
+    """Mirror of NerfHipResampleArgs (include/nerf_hip.h)."""
+    _fields_ = [("n_rays", ctypes.c_int64), ("num_coarse", ctypes.c_int32), ("num_fine", ctypes.c_int32),
+                ("t_coarse", _f32p), ("weights", _f32p), ("u", _f32p), ("pdf_floor", ctypes.c_float),
+                ("t_union", _f32p)]
+
+
 _lib = None
 
 
@@ -81,6 +88,8 @@ def lib():
     handle.nerf_hip_render_backward.argtypes = [ctypes.POINTER(BackwardArgs), ctypes.c_void_p]
     handle.nerf_hip_gather_pixel_rays.restype = ctypes.c_int
     handle.nerf_hip_gather_pixel_rays.argtypes = [ctypes.POINTER(GatherArgs), ctypes.c_void_p]
+    handle.nerf_hip_resample_pdf.restype = ctypes.c_int
+    handle.nerf_hip_resample_pdf.argtypes = [ctypes.POINTER(ResampleArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -95,7 +104,8 @@ def lib():
 EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_packed_bytes",
            "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
            "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
-           "nerf_hip_gather_pixel_rays", "nerf_hip_timing", "nerf_hip_timing_read")
+           "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_timing",
+           "nerf_hip_timing_read")
 
 
 def check(rc, what):

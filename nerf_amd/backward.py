@@ -17,7 +17,7 @@ class RenderRaysFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode,
-                *params):
+                t_values, want_weights, *params):
         lib = _lib.lib()
         n_rays, device = rays_o.shape[0], rays_o.device
         ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
@@ -26,25 +26,29 @@ class RenderRaysFunction(torch.autograd.Function):
         if rng_mode:
             rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, model._philox_calls)
             model._philox_calls += 1
-        rgb, seg, _, _, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
-                                          u=u, noise=noise, density_noise_std=density_noise_std,
-                                          rng_mode=rng_mode, rng_state=rng_state,
-                                          train_workspace=workspace)
+        rgb, seg, _, _, weights = model._launch(n_rays, num_samples, device, rays_o=rays_o,
+                                                rays_d=rays_d, u=u, noise=noise,
+                                                density_noise_std=density_noise_std, rng_mode=rng_mode,
+                                                rng_state=rng_state, t_values=t_values,
+                                                want_weights=want_weights, train_workspace=workspace)
+        if weights is None:
+            weights = rgb.new_empty(0)
         ctx.model = model
-        ctx.call = (rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode, rng_state)
+        ctx.call = (rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode, rng_state,
+                    t_values)
         ctx.workspace = workspace
         ctx.packed = model.packed_parameters()      # the image this forward used
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(rgb, seg)
-        ctx.mark_non_differentiable()
-        return rgb, seg
+        ctx.mark_non_differentiable(weights)
+        return rgb, seg, weights
 
     @staticmethod
-    def backward(ctx, d_rgb, d_seg):
+    def backward(ctx, d_rgb, d_seg, _d_weights):
         lib = _lib.lib()
         model = ctx.model
         rgb, seg = ctx.saved_tensors
-        rays_o, rays_d, num_samples, u, noise, std, rng_mode, rng_state = ctx.call
+        rays_o, rays_d, num_samples, u, noise, std, rng_mode, rng_state, t_values = ctx.call
         n_rays, device = rays_o.shape[0], rays_o.device
         if d_rgb is None:
             d_rgb = torch.zeros_like(rgb)
@@ -54,7 +58,7 @@ class RenderRaysFunction(torch.autograd.Function):
 
         args = _lib.BackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, u=u,
-                         noise=noise, density_noise_std=std, rng_mode=rng_mode, rng_state=rng_state,
+                         t_values=t_values, noise=noise, density_noise_std=std, rng_mode=rng_mode, rng_state=rng_state,
                          packed=ctx.packed, rgb=rgb, seg=seg, train_workspace=ctx.workspace)
         grad = torch.empty(lib.nerf_hip_grad_elements(), dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
@@ -73,4 +77,4 @@ class RenderRaysFunction(torch.autograd.Function):
             grads.append(grad[off:off + n].view(shape))
             off += n
         model.last_flat_grad = grad
-        return (None,) * 8 + tuple(grads)
+        return (None,) * 10 + tuple(grads)

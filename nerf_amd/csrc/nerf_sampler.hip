@@ -59,3 +59,89 @@ extern "C" int nerf_hip_gather_pixel_rays(const NerfHipGatherArgs* args, void* s
     hipLaunchKernelGGL(nerf_gather_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, g);
     return nerf_common::check_hip(hipGetLastError(), "gather_pixel_rays launch");
 }
+
+// ---------------------------------------------------------------------------------------------
+// inverse-CDF resampling for the hierarchical (coarse -> fine) configuration
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxPosts = 1024;
+
+// One wave per ray.  CDF by a wave-wide shuffle scan over the intervals (64 per step with a
+// carry), kept in LDS; every fine sample then binary-searches it; the union is a merge of two
+// sorted lists done by rank: rank(fine k) = k + #coarse posts <= it, rank(coarse i) = i + #fine
+// samples < it, both read off the same monotone map u <-> t.
+__global__ __launch_bounds__(256) void nerf_resample_kernel(const NerfHipResampleArgs ra) {
+    __shared__ float cdf_s[4][kMaxPosts];
+    __shared__ float uf_s[4][kMaxPosts];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+    if (ray >= ra.n_rays) return;
+    const int Sc = ra.num_coarse, Sf = ra.num_fine, P = Sc - 1;
+    const float* w = ra.weights + ray * P;
+    const float* tc = ra.t_coarse + ray * Sc;
+    float* cdf = cdf_s[wave];
+    float* uf = uf_s[wave];
+
+    // inclusive scan of (w + floor) -> cdf[i + 1]
+    float carry = 0.f;
+    for (int base = 0; base < P; base += 64) {
+        const int i = base + lane;
+        float v = i < P ? w[i] + ra.pdf_floor : 0.f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float up = __shfl_up(v, d);
+            if (lane >= d) v += up;
+        }
+        if (i < P) cdf[i + 1] = carry + v;
+        carry += __shfl(v, 63);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const float total = carry;
+    for (int i = lane; i <= P; i += 64) cdf[i] = i == P ? 1.0f : cdf[i] / total;
+    for (int k = lane; k < Sf; k += 64)
+        uf[k] = ra.u != nullptr ? ra.u[ray * Sf + k] : ((float)k + 0.5f) / (float)Sf;
+    __builtin_amdgcn_wave_barrier();
+
+    float* out = ra.t_union + ray * (int64_t)(Sc + Sf);
+    // fine samples: interval idx with cdf[idx] <= u < cdf[idx + 1]
+    for (int k = lane; k < Sf; k += 64) {
+        const float u = uf[k];
+        int lo = 0, hi = P;                       // invariant: cdf[lo] <= u < cdf[hi] (cdf[P] = 1 > u)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid; else hi = mid;
+        }
+        const float c0 = cdf[lo], c1 = cdf[lo + 1];
+        const float den = c1 - c0;
+        const float frac = den > 0.f ? (u - c0) / den : 0.f;
+        const float t0 = tc[lo], t1 = tc[lo + 1];
+        out[k + lo + 1] = t0 + frac * (t1 - t0);
+    }
+    // coarse fenceposts: rank = i + #fine samples with u < cdf[i]
+    for (int i = lane; i < Sc; i += 64) {
+        const float c = cdf[i];
+        int lo = 0, hi = Sf;                      // first k in [0, Sf] with uf[k] >= c
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uf[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        out[i + lo] = tc[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_hip_resample_pdf(const NerfHipResampleArgs* args, void* stream) {
+    if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "resample_pdf: null args");
+    const NerfHipResampleArgs& r = *args;
+    if (r.n_rays == 0) return NERF_HIP_OK;
+    if (r.n_rays < 0 || r.t_coarse == nullptr || r.weights == nullptr || r.t_union == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "resample_pdf: null pointer or negative n_rays");
+    if (r.num_coarse < 2 || r.num_coarse > kMaxPosts || r.num_fine < 1 || r.num_fine > kMaxPosts)
+        return nerf_common::fail(NERF_HIP_EINVAL, "resample_pdf: sample counts out of range");
+    const int64_t blocks = (r.n_rays + 3) / 4;
+    hipLaunchKernelGGL(nerf_resample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r);
+    return nerf_common::check_hip(hipGetLastError(), "resample_pdf launch");
+}

@@ -272,7 +272,7 @@ class NeRF(nn.Module):
     def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
                 ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
                 want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None,
-                train_workspace=None):
+                train_workspace=None, want_weights=False):
         lib = _lib.lib()
         packed = self.packed_parameters()
         P = num_samples - 1
@@ -284,6 +284,8 @@ class NeRF(nn.Module):
         if per_sample:
             mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
             raw = torch.empty(n_rays, P, 54, dtype=torch.float32, device=device)
+            weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
+        elif want_weights:
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         if rng_mode and rng_state is None:
             rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_calls)
@@ -347,11 +349,93 @@ class NeRF(nn.Module):
                                          density_noise_std)
         u = None if u is None else u.detach().reshape(n_rays, num_samples).contiguous()
         noise = None if noise is None else noise.detach().reshape(n_rays, num_samples - 1).contiguous()
-        from .autograd import render_rays_function            # local: autograd layer is optional
-        rgb, seg = render_rays_function(self, flat_o, flat_d, num_samples, u, noise,
-                                        float(density_noise_std), mode)
+        from .autograd import render_rays_function
+        rgb, seg, _ = render_rays_function(self, flat_o, flat_d, num_samples, u, noise,
+                                           float(density_noise_std), mode)
         return (rgb.reshape(*lead, 1, self.color_outputs),
                 seg.reshape(*lead, 1, self.segmentation_outputs))
+
+    # ---- hierarchical sampling (BASELINE config 3; parity unpinned, see include/nerf_hip.h) -----
+
+    def resample_fenceposts(self, t_coarse, weights, num_fine, u=None, pdf_floor=1e-5):
+        """Sorted union [N, S_c + num_fine] of the coarse fenceposts ``t_coarse`` [N,S_c] and
+        ``num_fine`` fenceposts drawn by inverse-transform sampling from the piecewise-constant
+        PDF that the coarse compositing ``weights`` [N,S_c-1] define (Mildenhall et al. 2020,
+        section 5.2).  ``u`` [N,num_fine]: ascending uniforms in [0,1); default (k + 0.5)/num_fine."""
+        _require_device(t_coarse, "t_coarse"), _require_device(weights, "weights")
+        n_rays, num_coarse = t_coarse.shape
+        out = torch.empty(n_rays, num_coarse + num_fine, dtype=torch.float32, device=t_coarse.device)
+        args = _lib.ResampleArgs()
+        args.n_rays, args.num_coarse, args.num_fine = n_rays, num_coarse, int(num_fine)
+        t_coarse, weights = t_coarse.detach().contiguous(), weights.detach().contiguous()
+        u = None if u is None else u.detach().contiguous()
+        args.t_coarse, args.weights, args.u = _lib.ptr(t_coarse), _lib.ptr(weights), _lib.ptr(u)
+        args.pdf_floor, args.t_union = float(pdf_floor), _lib.ptr(out)
+        with torch.cuda.device(out.device):
+            stream = torch.cuda.current_stream(out.device).cuda_stream
+            _lib.check(_lib.lib().nerf_hip_resample_pdf(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_resample_pdf")
+        return out
+
+    def render_rays_hierarchical(self, rays_o, rays_d, num_coarse, num_fine, states_x=None,
+                                 states_d=None, randomly_sample=False, density_noise_std=0.0):
+        """Two-stage render: ``num_coarse`` log-spaced fenceposts, then the sorted union with
+        ``num_fine`` fenceposts resampled from the coarse weights.  Returns
+        (image [N,2,3], segmentation [N,2,50]) — coarse and fine on the reference's stage axis
+        (model.py:645, :667-668); the same network serves both stages.  Gradients flow through both
+        renders, not through the sampling (the paper's recipe)."""
+        from .autograd import render_rays_function
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        flat_o = rays_o.detach().reshape(-1, 3).contiguous()
+        flat_d = rays_d.detach().reshape(-1, 3).contiguous()
+        n_rays, dev = flat_o.shape[0], flat_o.device
+        t_c = self.sample_along_rays(flat_o, flat_d, num_coarse, randomly_sample=randomly_sample)
+        t_c = t_c.contiguous()
+
+        def noise_for(num_samples):
+            draw = torch.randn(n_rays, num_samples - 1, dtype=torch.float32, device=dev)
+            return draw if density_noise_std != 0.0 else None
+
+        std = float(density_noise_std)
+        rgb_c, seg_c, w_c = render_rays_function(self, flat_o, flat_d, num_coarse, None,
+                                                 noise_for(num_coarse), std, 0, t_values=t_c,
+                                                 want_weights=True)
+        u_f = None
+        if randomly_sample:
+            k = torch.arange(num_fine, dtype=torch.float32, device=dev)
+            u_f = (k + torch.rand(n_rays, num_fine, dtype=torch.float32, device=dev)) / num_fine
+            u_f = u_f.clamp(max=1.0 - 1e-6)
+        t_u = self.resample_fenceposts(t_c, w_c, num_fine, u=u_f)
+        rgb_f, seg_f, _ = render_rays_function(self, flat_o, flat_d, num_coarse + num_fine, None,
+                                               noise_for(num_coarse + num_fine), std, 0, t_values=t_u)
+        lead = rays_o.shape[:-1]
+        image = torch.stack([rgb_c, rgb_f], dim=-2).reshape(*lead, 2, self.color_outputs)
+        seg = torch.stack([seg_c, seg_f], dim=-2).reshape(*lead, 2, self.segmentation_outputs)
+        return image, seg
+
+    def render_image_hierarchical(self, camera_o, camera_r, image_h, image_w, focal_length, num_coarse,
+                                  num_fine, max_chunk_size=262144, randomly_sample=False,
+                                  density_noise_std=0.0):
+        """``render_image`` with two-stage sampling: returns the LAST stage, like the reference's
+        ``x[:, -1]`` (model.py:757): (image [B,H,W,3], segmentation [B,H,W,50])."""
+        _require_device(camera_o, "camera_o"), _require_device(camera_r, "camera_r")
+        batch = camera_o.shape[0]
+        rays = self.generate_rays(image_h, image_w, focal_length, dtype=camera_o.dtype,
+                                  device=camera_o.device)
+        rays = torch.broadcast_to(rays.unsqueeze(0), [batch, image_h, image_w, 3])
+        cam_o = torch.broadcast_to(camera_o[:, None, None, :], [batch, image_h, image_w, 3])
+        cam_r = torch.broadcast_to(camera_r[:, None, None, :, :], [batch, image_h, image_w, 3, 3])
+        rays_o, rays_d = self.rays_to_world_coordinates(rays, cam_o, cam_r)
+        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        images, segs = [], []
+        for o_i, d_i in zip(torch.split(rays_o, max_chunk_size), torch.split(rays_d, max_chunk_size)):
+            img, seg = self.render_rays_hierarchical(o_i, d_i, num_coarse, num_fine,
+                                                     randomly_sample=randomly_sample,
+                                                     density_noise_std=density_noise_std)
+            images.append(img[:, -1])
+            segs.append(seg[:, -1])
+        return (torch.cat(images).reshape(batch, image_h, image_w, self.color_outputs),
+                torch.cat(segs).reshape(batch, image_h, image_w, self.segmentation_outputs))
 
     def render_image(self, camera_o, camera_r, image_h, image_w, focal_length, num_samples,
                      states_x=None, states_d=None, max_chunk_size=1024, randomly_sample=False,

@@ -293,3 +293,47 @@ def flops_per_sample(cfg=None):
 
 
 assert math.isclose(flops_per_sample(), 601088)
+
+
+# --------------------------------------------------------------------------
+# hierarchical sampling — PARITY UNPINNED: the reference has no code for it (only docstrings,
+# model.py:191-193).  This restates Mildenhall et al. 2020 section 5.2 and is the spec the HIP
+# resampler is tested against.
+# --------------------------------------------------------------------------
+
+def resample_fenceposts(t_coarse, weights, num_fine, u=None, pdf_floor=1e-5):
+    """Sorted union of the coarse fenceposts [N,S_c] with num_fine fenceposts drawn by inverse
+    transform sampling from the piecewise-constant PDF of weights [N,S_c-1]."""
+    w = weights + pdf_floor
+    cdf = torch.cumsum(w, dim=-1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf / cdf[..., -1:]], dim=-1)
+    cdf[..., -1] = 1.0
+    if u is None:
+        u = ((torch.arange(num_fine, dtype=t_coarse.dtype) + 0.5) / num_fine).expand(
+            t_coarse.shape[0], num_fine)
+    idx = (torch.searchsorted(cdf.contiguous(), u.contiguous(), right=True) - 1).clamp(
+        0, weights.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, -1, idx), torch.gather(cdf, -1, idx + 1)
+    t0, t1 = torch.gather(t_coarse, -1, idx), torch.gather(t_coarse, -1, idx + 1)
+    den = c1 - c0
+    frac = torch.where(den > 0, (u - c0) / den, torch.zeros_like(den))
+    t_fine = t0 + frac * (t1 - t0)
+    return torch.sort(torch.cat([t_coarse, t_fine], dim=-1), dim=-1).values
+
+
+def render_rays_t(params, cfg, rays_o, rays_d, t):
+    """render_rays on explicit fenceposts t [N,S] (deterministic): rgb, seg, weights."""
+    means, covs, h, density, color, seg = field(params, cfg, rays_o, rays_d, t)
+    weights = composite_weights(means, density)
+    rgb = (weights * torch.sigmoid(color)).sum(dim=-2)
+    seg_out = (torch.log(weights + 1e-10) + torch.log_softmax(seg, dim=-1)).logsumexp(dim=-2)
+    return rgb, seg_out, weights[..., 0]
+
+
+def render_rays_hierarchical(params, cfg, rays_o, rays_d, num_coarse, num_fine):
+    """Coarse + fine (sorted union) deterministic render: rgb [N,2,3], seg [N,2,50], t_union."""
+    t_c = sample_t(params, rays_o.shape[0], num_coarse)
+    rgb_c, seg_c, w_c = render_rays_t(params, cfg, rays_o, rays_d, t_c)
+    t_u = resample_fenceposts(t_c, w_c, num_fine)
+    rgb_f, seg_f, _ = render_rays_t(params, cfg, rays_o, rays_d, t_u)
+    return torch.stack([rgb_c, rgb_f], dim=-2), torch.stack([seg_c, seg_f], dim=-2), t_u
