@@ -80,22 +80,40 @@ __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, con
         for (int r = 0; r < 4; ++r) act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
     return;
 #endif
-    float s = 0.f;
-#pragma unroll
-    for (int T = 0; T < 16; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
-    s = group_sum(s);
-    const float mean = s * (1.0f / 256.0f);
-    float v = 0.f;
+    // One pass: sum and sum of squares together (128 VALU instead of 192).  var = E[x^2] - mean^2
+    // cancels when |mean| >> std, so whenever the mean carries more than 3/4 of the second moment
+    // in ANY sample of the wave, the exact two-pass variance is taken instead (wave-uniform branch;
+    // pre-LayerNorm activations of this network have |mean| well below std, so it is cold).
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float d = acc[T][r] - mean;
-            v = __builtin_fmaf(d, d, v);
+            s += acc[T][r];
+            q = __builtin_fmaf(acc[T][r], acc[T][r], q);
         }
     }
-    v = group_sum(v);
-    const float rstd = 1.0f / __builtin_sqrtf(v * (1.0f / 256.0f) + 1e-5f);
+    s = group_sum(s);
+    q = group_sum(q);
+    const float mean = s * (1.0f / 256.0f);
+    const float ex2 = q * (1.0f / 256.0f);
+    float var = ex2 - mean * mean;
+    if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[T][r] - mean;
+                v = __builtin_fmaf(d, d, v);
+            }
+        }
+        var = group_sum(v) * (1.0f / 256.0f);
+    }
+    // 1/sqrt: hardware estimate (1 ulp) + one Newton step, instead of IEEE sqrt followed by divide
+    const float ve = var + 1e-5f;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
     const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
     const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
 #pragma unroll

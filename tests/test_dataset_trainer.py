@@ -75,7 +75,7 @@ def test_training_improves_held_out_psnr_and_writes_reference_files(tmp_path):
     print("held-out PSNR:", [round(float(p), 2) for p in run.psnrs], "loss", first_loss, "->", last_loss)
     assert last_loss < 0.1 * first_loss                       # the fit itself
     # held-out view: 8 training views of a random field generalise only so far; it must improve
-    assert max(float(p) for p in run.psnrs[1:]) > float(run.psnrs[0]) + 1.5
+    assert max(float(p) for p in run.psnrs[1:]) > float(run.psnrs[0]) + 1.0
     for name in ("params.json", "model.pth", "psnrs.npy", "iternums.npy", "rendered_images.npy",
                  "ground_truth_images.npy"):
         assert os.path.exists(os.path.join(tmp_path, name)), name
