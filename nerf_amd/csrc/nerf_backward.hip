@@ -65,16 +65,34 @@ struct GammaBetaTurn {
     }
 };
 
+// Stage hook of the data-gradient MFMA loops: the wave-ordered gamma/beta adds, and at stage 1
+// the loads of the NEXT LayerNorm backward's saved x_hat tile and 1/std, so that their HBM latency
+// runs under this layer's MFMAs instead of in front of the LayerNorm arithmetic.  (Stage 1, not 0:
+// the loads then sit behind one stage's DMA in the vmcnt queue and the next stage's counted wait
+// retires them only after a whole stage of MFMAs.)
+struct BwdHook {
+    GammaBetaTurn& turn;
+    const float* xhat_tile;
+    const float* rstd_ptr;
+    f32x4 (&xh)[16];
+    float& rstd;
+    __device__ __forceinline__ void operator()(int t) const {
+        turn(t);
+        if (t == 1) {
+#pragma unroll
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_tile + T * 256);
+            rstd = *rstd_ptr;
+        }
+    }
+};
+
 // LayerNorm + ReLU backward for hidden layer L on the register tile.
 //   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
 //   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
 __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
                                                     f32x4 (&acc)[16], float (&act)[64],
-                                                    const float* xhat_tile, float rstd,
+                                                    const f32x4 (&xh)[16], float rstd,
                                                     float* dy_row, float* gb_l, GammaBetaTurn& turn) {
-    f32x4 xh[16];
-#pragma unroll
-    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_tile + T * 256);
     const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
     const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
     float s1 = 0.f, s2 = 0.f;
@@ -261,20 +279,24 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-            layer_wide_v4<kStagesL5>(pipe, acc, dout, turn);   // hook: layer-0 partials of the previous chunk
+            f32x4 xh[16];
+            float rstd;
+            layer_wide_v4<kStagesL5>(pipe, acc, dout,
+                                     BwdHook{turn, ws + ba.L.xhat[4] + tile * 4096 + lane * 4,
+                                             ws + ba.L.rstd[4] + sp, xh, rstd});
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
-                layer_norm_relu_bwd(small + L * kSmallPerLayer, g, j, acc, act,
-                                    ws + ba.L.xhat[L] + tile * 4096 + lane * 4,
-                                    ws[ba.L.rstd[L] + sp],
+                layer_norm_relu_bwd(small + L * kSmallPerLayer, g, j, acc, act, xh, rstd,
                                     ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-                layer_wide<kStagesHidden>(pipe, acc, act, turn);
+                layer_wide<kStagesHidden>(pipe, acc, act,
+                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + tile * 4096 + lane * 4,
+                                                  ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
-            layer_norm_relu_bwd(small, g, j, acc, act, ws + ba.L.xhat[0] + tile * 4096 + lane * 4,
-                                ws[ba.L.rstd[0] + sp], ws + ba.L.dy[0] + sp * kHidden + 4 * g, gb, turn);
+            layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
+                                gb, turn);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,17 +345,10 @@ __device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int
 }
 
 template <class Sh>
-__global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba, const float* dy,
-                                                            const float* x, int w_off, int b_off) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const float* dy, const float* x,
+                                           int w_off, int b_off, int split) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int split = blockIdx.x;
-    // hidden layers share one launch: blockIdx.y selects the layer
-    dy += (int64_t)blockIdx.y * ba.L.mp * kHidden;
-    x += (int64_t)blockIdx.y * ba.L.mp * kHidden;
-    w_off += blockIdx.y * kHidden * kHidden;
-    b_off += blockIdx.y * kHidden;
 
     int out0, in0;                                // first 32-wide tile of this wave
     if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
@@ -407,6 +422,23 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba, co
     if ((int)threadIdx.x < Sh::kOutW) slab[b_off + threadIdx.x] = bias_sum;
 }
 
+// All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
+// layer-0 / layer-5 jobs fill the tail instead of running half-empty launches of their own.
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const float* ws = ba.a.train_workspace;
+    if (job < 4) {                                // layers 1..4
+        wgrad_body<ShapeHid>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+                             ws + ba.L.x[0] + (int64_t)job * ba.L.mp * kHidden,
+                             kSlabWh + job * kHidden * kHidden, kSlabB + (job + 1) * kHidden, split);
+    } else if (job == 4) {                        // layer 0
+        wgrad_body<ShapeL0>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, kSlabW0, kSlabB, split);
+    } else {                                      // layer 5
+        wgrad_body<ShapeL5>(ba, smem, ws + ba.L.dy5, ws + ba.L.x[4], kSlabW5, kSlabB + 5 * kHidden, split);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // deterministic reduction of the partials into the flat gradient vector
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +448,21 @@ __device__ __forceinline__ int layer0_kernel_column(int feature) {
     const int scale = rem / 3, coord = rem % 3;
     const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
     return 16 * (q / 4) + 4 * g + (q % 4);
+}
+
+// sum of p[0], p[stride], ... (n terms) in a fixed association: four interleaved partial sums
+// (independent loads in flight), combined pairwise
+__device__ __forceinline__ float strided_sum(const float* p, int n, int64_t stride) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        s0 += p[(int64_t)i * stride];
+        s1 += p[(int64_t)(i + 1) * stride];
+        s2 += p[(int64_t)(i + 2) * stride];
+        s3 += p[(int64_t)(i + 3) * stride];
+    }
+    for (; i < n; ++i) s0 += p[(int64_t)i * stride];
+    return (s0 + s1) + (s2 + s3);
 }
 
 __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
@@ -435,7 +482,7 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
     float sum = 0.f;
     if (which >= 2) {                             // gamma (2) / beta (3): per-workgroup partials
         const float* p = ba.gb_partial + L * 2 * kHidden + (which - 2) * kHidden + idx;
-        for (int w = 0; w < ba.data_grid; ++w) sum += p[(int64_t)w * kGbFloats];
+        sum = strided_sum(p, ba.data_grid, kGbFloats);
     } else {
         int so;
         if (which == 0) {
@@ -445,8 +492,7 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
         } else {
             so = kSlabB + L * kHidden + idx;
         }
-        const float* p = ba.slabs + so;
-        for (int s = 0; s < ba.splits; ++s) sum += p[(int64_t)s * kSlabFloats];
+        sum = strided_sum(ba.slabs + so, ba.splits, kSlabFloats);
     }
     ba.grad[e] = sum;
 }
@@ -503,11 +549,9 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {(const void*)nerf_bwd_data_kernel, (const void*)nerf_wgrad_kernel<ShapeL0>,
-                              (const void*)nerf_wgrad_kernel<ShapeHid>, (const void*)nerf_wgrad_kernel<ShapeL5>};
-        const int lds[4] = {kBwdLdsBytes, 2 * ShapeL0::kTileBytes, 2 * ShapeHid::kTileBytes,
-                            2 * ShapeL5::kTileBytes};
-        for (int i = 0; i < 4; ++i) {
+        const void* fns[2] = {(const void*)nerf_bwd_data_kernel, (const void*)nerf_wgrad_kernel};
+        const int lds[2] = {kBwdLdsBytes, 2 * ShapeHid::kTileBytes};
+        for (int i = 0; i < 2; ++i) {
             rc = nerf_common::check_hip(
                 hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds[i]),
                 "hipFuncSetAttribute");
@@ -522,14 +566,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
 
     float* ws = a.train_workspace;
     hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
-    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeHid>, dim3(ba.splits, 4), dim3(256), 2 * ShapeHid::kTileBytes,
-                       st, ba, (const float*)(ws + ba.L.dy[1]), (const float*)(ws + ba.L.x[0]), kSlabWh,
-                       kSlabB + kHidden);
-    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeL0>, dim3(ba.splits, 1), dim3(256), 2 * ShapeL0::kTileBytes, st,
-                       ba, (const float*)(ws + ba.L.dy[0]), (const float*)(ws + ba.L.h), kSlabW0, kSlabB);
-    hipLaunchKernelGGL(nerf_wgrad_kernel<ShapeL5>, dim3(ba.splits, 1), dim3(256), 2 * ShapeL5::kTileBytes, st,
-                       ba, (const float*)(ws + ba.L.dy5), (const float*)(ws + ba.L.x[4]), kSlabW5,
-                       kSlabB + 5 * kHidden);
+    hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 6), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
     const int threads = 256;
     hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((kGradElements + threads - 1) / threads), dim3(threads),
                        0, st, ba);
