@@ -72,6 +72,54 @@ def cpu_baseline(rows=32):
                       f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
 
 
+def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
+    """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
+    backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
+    from nerf_amd import NeRF
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
+    target = torch.rand(rays, 3, device=dev)
+
+    def step():
+        pixels, _ = model.render_rays(o, d, samples, randomly_sample=True, density_noise_std=1.0)
+        loss = ((pixels - target.unsqueeze(1)) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    tflops = 3 * FLOP_PER_SAMPLE * rays * (samples - 1) / dt / 1e12
+    return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
+            "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
+            "tflops_fwd_dgrad_wgrad": tflops, "frac_of_fp32_mfma_peak": tflops / PEAK_TFLOPS_FP32_MFMA}
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/*_pmc_summary.json; FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the
+    timed process, so this is the last profiled value, or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            best = ((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT))
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +195,7 @@ def main():
     if rank == 0:
         evaluated = rays_per_rank * (SAMPLES - 1)
         achieved = evaluated * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
+        traffic = profiled_traffic() if (world == 1 and args.scaling == "weak") else None
         line = {
             "metric": "ray-samples/sec at 800x800x128",
             "value": value,
@@ -174,7 +223,10 @@ def main():
                 "peak": PEAK_TFLOPS_FP32_MFMA,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS_FP32_MFMA if achieved else None,
-                "traffic": None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_unit": "bytes/launch",
+                "traffic_source": traffic[1] if traffic else None,
+                "algorithmic_bytes": rays_per_rank * (12 + 200) + 48,
                 "kernel": "nerf_render_fwd_kernel",
                 "kernel_ms": kernel_ms,
                 "launches_timed": launches,
@@ -183,6 +235,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
+            line["train_step"] = train_step_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if distributed:
