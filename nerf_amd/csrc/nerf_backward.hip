@@ -386,19 +386,34 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
         const float* dyt = (const float*)cur;
         const float* xt = (const float*)(cur + Sh::kDyBytes);
         const int i = lane & 31, kk = lane >> 5;
-#pragma unroll 4
+        // operands of k-step s+1 are read right after the first MFMA of k-step s (two register
+        // sets), so an LDS read always has a whole k-step of MFMAs to land
+        float af[2][Sh::kTo], bf[2][Sh::kTi];
+#pragma unroll
+        for (int a = 0; a < Sh::kTo; ++a) af[0][a] = dyt[kk * Sh::kOutW + 32 * (out0 + a) + i];
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = xt[kk * Sh::kInW + 32 * (in0 + b) + i];
+#pragma unroll
         for (int step = 0; step < kKs / 2; ++step) {
-            const int srow = 2 * step + kk;
-            float af[Sh::kTo], bf[Sh::kTi];
+            const int cur = step & 1, nxt = cur ^ 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bf[cur][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < kKs / 2) {
+                const int srow = 2 * (step + 1) + kk;
 #pragma unroll
-            for (int a = 0; a < Sh::kTo; ++a) af[a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
+                for (int a = 0; a < Sh::kTo; ++a) af[nxt][a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
 #pragma unroll
-            for (int b = 0; b < Sh::kTi; ++b) bf[b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
+                for (int b = 0; b < Sh::kTi; ++b) bf[nxt][b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < Sh::kTo; ++a)
 #pragma unroll
                 for (int b = 0; b < Sh::kTi; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    if (a + b > 0)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b],
+                                                                         0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if ((int)threadIdx.x < Sh::kOutW) {       // bias gradient: column sums of dY
 #pragma unroll 8
