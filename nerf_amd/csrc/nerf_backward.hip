@@ -562,18 +562,12 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* fns[2] = {(const void*)nerf_bwd_data_kernel, (const void*)nerf_wgrad_kernel};
-        const int lds[2] = {kBwdLdsBytes, 2 * ShapeHid::kTileBytes};
-        for (int i = 0; i < 2; ++i) {
-            rc = nerf_common::check_hip(
-                hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds[i]),
-                "hipFuncSetAttribute");
-            if (rc) return rc;
-        }
-        attr_set = true;
-    }
+    static unsigned done_data = 0, done_wgrad = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_kernel, kBwdLdsBytes, device, &done_data);
+    if (rc) return rc;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_kernel, 2 * ShapeHid::kTileBytes, device,
+                                         &done_wgrad);
+    if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ba.groups) grid = ba.groups;
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;

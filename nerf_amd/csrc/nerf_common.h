@@ -58,9 +58,14 @@ struct Timing {
         on() = v;
         return NERF_HIP_OK;
     }
+    static constexpr size_t kMaxPairs = 8192;   // un-read launches beyond this are not timed
     static void before(hipStream_t st) {
         pending() = nullptr;
         if (!on()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (pairs().size() >= kMaxPairs) return;
+        }
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
         hipEventRecord(e, st);
@@ -103,6 +108,18 @@ struct Timing {
         return NERF_HIP_OK;
     }
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes
+// are per device, and a process may drive more than one.
+inline int ensure_dynamic_lds(const void* fn, int bytes, int device, unsigned* done_mask) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    if (device >= 0 && device < 32 && (*done_mask & (1u << device))) return NERF_HIP_OK;
+    const int rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+                             "hipFuncSetAttribute");
+    if (rc == NERF_HIP_OK && device >= 0 && device < 32) *done_mask |= (1u << device);
+    return rc;
+}
 
 }  // namespace nerf_common
 

@@ -487,20 +487,13 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        rc = nerf_common::check_hip(
-            hipFuncSetAttribute((const void*)nerf_render_fwd_kernel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),
-            "hipFuncSetAttribute");
-        if (rc) return rc;
-        rc = nerf_common::check_hip(
-            hipFuncSetAttribute((const void*)nerf_render_fwd_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes),
-            "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static unsigned done_infer = 0, done_train = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false>, kLdsBytes, device,
+                                         &done_infer);
+    if (rc) return rc;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true>, kLdsBytes, device,
+                                         &done_train);
+    if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64 KiB LDS, <= 256 VGPRs)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;

@@ -209,3 +209,62 @@ def test_philox_path_statistics(dev):
     a, b = torch.stack(draws).mean(0), torch.stack(draws_t).mean(0)
     assert not torch.equal(draws[0], draws[1])
     assert (a - b).abs().mean() < 0.02
+
+
+def test_batched_poses_nondefault_box_and_focal(dev):
+    """render_image with B = 3 poses (the torch.cross quirk of get_rotation_matrix included), a
+    scene box other than +/-20 (changes the fencepost scale) and a constructor focal length that
+    differs from render_image's (r_dot uses the constructor's, model.py:546)."""
+    from nerf_amd import NeRF
+    params = golden_params(3.0)
+    params["rays_min"] = torch.tensor([[[-6.0, -5.0, -4.0]]])
+    params["rays_max"] = torch.tensor([[[6.0, 7.0, 8.0]]])
+    model = NeRF(focal_length=50.0, min_x=-6.0, max_x=6.0, min_y=-5.0, max_y=7.0, min_z=-4.0, max_z=8.0)
+    model.load_state_dict(params)
+    model = model.to(dev)
+    yaw, elev = torch.tensor([0.3, 1.9, -2.2]), torch.tensor([0.4, 0.2, 0.9])
+    pos = NeRF.spherical_to_cartesian(yaw, elev) * 3.0
+    eye = -pos / pos.norm(dim=-1, keepdim=True)
+    z = torch.tensor([[0.0, 0.0, 1.0]]).expand_as(eye)
+    up = z - (z * eye).sum(-1, keepdim=True) * eye
+    rot = NeRF.get_rotation_matrix(eye, up / up.norm(dim=-1, keepdim=True))
+    cfg = dict(CFG, focal_length=50.0)
+    with torch.no_grad():
+        img, seg = model.render_image(pos.to(dev), rot.to(dev), 9, 11, 13.0, 40)
+        ref_img, ref_seg = O.render_image(params, cfg, pos, rot, 9, 11, 13.0, 40)
+        o, d = O.image_rays(pos, rot, 9, 11, 13.0)
+        _, _, st = O.render_rays(params, cfg, o, d, 40, return_stages=True)
+    assert img.shape == (3, 9, 11, 3) and seg.shape == (3, 9, 11, 50)
+    ok = stable_rays(st["density"][:, -1, 0]).reshape(3, 9, 11)
+    assert (img.cpu() - ref_img)[ok].abs().max() <= 1e-5
+    assert (seg.cpu() - ref_seg)[ok].abs().max() <= 1e-4
+
+
+def test_degenerate_and_extreme_rays(dev):
+    """Zero direction (|d|^2 clamp of lift_gaussian, model.py:37), huge and tiny directions, far
+    origins: finite outputs that match the oracle."""
+    params = golden_params(3.0)
+    model = make_model(dev, params=params)
+    o = torch.tensor([[0.0, 0.0, 0.0], [1.0, 2.0, 3.0], [0.0, 0.0, 0.0], [30.0, -30.0, 10.0], [0.0, 0.0, 0.0]])
+    d = torch.tensor([[0.0, 0.0, 0.0], [1e-4, 0.0, 0.0], [50.0, 20.0, -70.0], [0.0, 1.0, 0.0], [0.6, 0.0, 0.8]])
+    with torch.no_grad():
+        rgb, seg = model.render_rays(o.to(dev), d.to(dev), 64)
+        ref_rgb, ref_seg, st = O.render_rays(params, CFG, o, d, 64, return_stages=True)
+    assert torch.isfinite(rgb).all() and torch.isfinite(seg).all()
+    ok = stable_rays(st["density"][:, -1, 0])
+    assert (rgb[:, 0].cpu() - ref_rgb)[ok].abs().max() <= 1e-5
+    assert (seg[:, 0].cpu() - ref_seg)[ok].abs().max() <= 1e-4
+
+
+def test_many_samples_per_ray(dev):
+    """S far above the tuned sizes (1025 fenceposts = 64 chunks per ray)."""
+    params = golden_params(3.0)
+    model = make_model(dev, params=params)
+    torch.manual_seed(21)
+    o, d = torch.randn(6, 3), torch.randn(6, 3)
+    with torch.no_grad():
+        rgb, seg = model.render_rays(o.to(dev), d.to(dev), 1025)
+        ref_rgb, ref_seg, st = O.render_rays(params, CFG, o, d, 1025, return_stages=True)
+    ok = stable_rays(st["density"][:, -1, 0])
+    assert (rgb[:, 0].cpu() - ref_rgb)[ok].abs().max() <= 2e-5
+    assert (seg[:, 0].cpu() - ref_seg)[ok].abs().max() <= 2e-4
