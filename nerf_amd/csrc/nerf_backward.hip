@@ -72,7 +72,7 @@ struct GammaBetaTurn {
 // retires them only after a whole stage of MFMAs.)
 struct BwdHook {
     GammaBetaTurn& turn;
-    const float* xhat_tile;
+    const float* xhat_row;      // this lane's 4 features of tile 0 in its sample's row
     const float* rstd_ptr;
     f32x4 (&xh)[16];
     float& rstd;
@@ -80,7 +80,7 @@ struct BwdHook {
         turn(t);
         if (t == 1) {
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_tile + T * 256);
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * 16);
             rstd = *rstd_ptr;
         }
     }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             f32x4 xh[16];
             float rstd;
             layer_wide_v4<kStagesL5>(pipe, acc, dout,
-                                     BwdHook{turn, ws + ba.L.xhat[4] + tile * 4096 + lane * 4,
+                                     BwdHook{turn, ws + ba.L.xhat[4] + sp * kHidden + 4 * g,
                                              ws + ba.L.rstd[4] + sp, xh, rstd});
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 layer_wide<kStagesHidden>(pipe, acc, act,
-                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + tile * 4096 + lane * 4,
+                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g,
                                                   ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
             layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
@@ -344,9 +344,11 @@ __device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int
     }
 }
 
-template <class Sh>
+// `x` rows are the layer's input: the encoded features (layer 0, kAffine false) or the saved x_hat
+// of the previous layer, turned into relu(gamma * x_hat + beta) as the operands are read from LDS.
+template <class Sh, bool kAffine>
 __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const float* dy, const float* x,
-                                           int w_off, int b_off, int split) {
+                                           const float* small_prev, int w_off, int b_off, int split) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -354,6 +356,20 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
     if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
     else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
     else { out0 = 0; in0 = 2 * wave; }
+
+    // gamma / beta of this lane's input features (feature f sits at [(f % 16) / 4][f / 16][f % 4]
+    // of the packed small image)
+    float ga[Sh::kTi], be[Sh::kTi];
+#pragma unroll
+    for (int b = 0; b < Sh::kTi; ++b) {
+        const int f = 32 * (in0 + b) + (lane & 31);
+        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
+        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
+        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
+    }
+    auto input = [&](float v, int b) {
+        return kAffine ? __builtin_fmaxf(__builtin_fmaf(v, ga[b], be[b]), 0.f) : v;
+    };
 
     f32x16 acc[Sh::kTo][Sh::kTi];
 #pragma unroll
@@ -392,7 +408,7 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
 #pragma unroll
         for (int a = 0; a < Sh::kTo; ++a) af[0][a] = dyt[kk * Sh::kOutW + 32 * (out0 + a) + i];
 #pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = xt[kk * Sh::kInW + 32 * (in0 + b) + i];
+        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = input(xt[kk * Sh::kInW + 32 * (in0 + b) + i], b);
 #pragma unroll
         for (int step = 0; step < kKs / 2; ++step) {
             const int cur = step & 1, nxt = cur ^ 1;
@@ -403,7 +419,8 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
 #pragma unroll
                 for (int a = 0; a < Sh::kTo; ++a) af[nxt][a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
 #pragma unroll
-                for (int b = 0; b < Sh::kTi; ++b) bf[nxt][b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
+                for (int b = 0; b < Sh::kTi; ++b)
+                    bf[nxt][b] = input(xt[srow * Sh::kInW + 32 * (in0 + b) + i], b);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -443,14 +460,17 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
     const float* ws = ba.a.train_workspace;
-    if (job < 4) {                                // layers 1..4
-        wgrad_body<ShapeHid>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
-                             ws + ba.L.x[0] + (int64_t)job * ba.L.mp * kHidden,
-                             kSlabWh + job * kHidden * kHidden, kSlabB + (job + 1) * kHidden, split);
-    } else if (job == 4) {                        // layer 0
-        wgrad_body<ShapeL0>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, kSlabW0, kSlabB, split);
-    } else {                                      // layer 5
-        wgrad_body<ShapeL5>(ba, smem, ws + ba.L.dy5, ws + ba.L.x[4], kSlabW5, kSlabB + 5 * kHidden, split);
+    const float* small = ba.a.packed + kBlobFloats;       // [layer][bias | gamma | beta][256]
+    if (job < 4) {                                // layers 1..4: input = LayerNorm+ReLU of layer job
+        wgrad_body<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+                                   ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
+                                   small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
+                                   kSlabB + (job + 1) * kHidden, split);
+    } else if (job == 4) {                        // layer 0: input = encoded features
+        wgrad_body<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
+    } else {                                      // layer 5: input = LayerNorm+ReLU of layer 4
+        wgrad_body<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                  kSlabW5, kSlabB + 5 * kHidden, split);
     }
 }
 

@@ -26,15 +26,17 @@ constexpr int kSamplesPerWave = 16;
 // saved-for-backward workspace (training forward writes it, backward reads/extends it)
 // padded sample index sp = (ray * chunks + c) * 16 + j ; "tile" tensors are stored exactly in
 // register order [chunk][T][lane][r] (1 KiB per store instruction), "row" tensors as
-// [sp][feature] (what the weight-gradient GEMM stages through LDS).
+// [sp][feature] (what the weight-gradient GEMM stages through LDS).  The post-ReLU activations
+// x = relu(gamma * x_hat + beta) are NOT saved: the weight-gradient kernel rebuilds them from
+// x_hat while it reads its operands (two VALU ops per operand instead of 1 KiB per sample and
+// layer of HBM writes in the forward).
 // ---------------------------------------------------------------------------------------------
 struct TrainLayout {
     int64_t mp;                 // padded samples = ceil4(n_rays) * chunks * 16
     int64_t h;                  // row  [mp, 96]   encoded inputs, kernel column order
-    int64_t x[5];               // row  [mp, 256]  input of layer L+1 (post LayerNorm+ReLU)
     int64_t dy[5];              // row  [mp, 256]  grad wrt pre-LayerNorm output of layer L
     int64_t dy5;                // row  [mp, 64]   grad wrt padded network output
-    int64_t xhat[5];            // tile [mp, 256]  normalised pre-affine activations
+    int64_t xhat[5];            // row  [mp, 256]  normalised pre-affine activations of layer L
     int64_t rstd[5];            // [mp]
     int64_t out;                // tile [mp, 64]   padded network output
     int64_t comp;               // [mp, 4]         alpha, T_exclusive, dist, density(+noise)
@@ -47,7 +49,6 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
     t.mp = rays4 * chunks * 16;
     int64_t off = 0;
     t.h = off; off += t.mp * kEncIn;
-    for (int i = 0; i < 5; ++i) { t.x[i] = off; off += t.mp * kHidden; }
     for (int i = 0; i < 5; ++i) { t.dy[i] = off; off += t.mp * kHidden; }
     t.dy5 = off; off += t.mp * kOutPad;
     for (int i = 0; i < 5; ++i) { t.xhat[i] = off; off += t.mp * kHidden; }

@@ -67,12 +67,12 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&acc)[4], const 
 
 // LayerNorm(256, eps 1e-5, affine, biased variance) + ReLU on the accumulator tile, result
 // written as the next layer's B operands.  A sample's 256 features sit in 64 registers of
-// each of the 4 lanes {j, j+16, j+32, j+48}.  Training also saves x_hat (register order),
-// the post-ReLU activations (row order, for the weight-gradient GEMM) and 1/std.
+// each of the 4 lanes {j, j+16, j+32, j+48}.  Training also saves x_hat (row order: the backward's
+// LayerNorm and, through the affine + ReLU, its weight-gradient operand) and 1/std.
 template <bool kTrain>
 __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, const f32x4 (&acc)[16],
-                                                float (&act)[64], float* save_xhat_tile,
-                                                float* save_x_row, float* save_rstd) {
+                                                float (&act)[64], float* save_xhat_row,
+                                                float* save_rstd) {
 #ifdef NERF_ABL_LN           /* timing experiment only: ReLU without the normalisation */
 #pragma unroll
     for (int T = 0; T < 16; ++T)
@@ -126,10 +126,7 @@ __device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, con
             xo[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
             act[4 * T + r] = xo[r];
         }
-        if (kTrain) {
-            *(f32x4*)(save_xhat_tile + T * 256) = xh;
-            *(f32x4*)(save_x_row + T * 16) = xo;
-        }
+        if (kTrain) *(f32x4*)(save_xhat_row + T * 16) = xh;
     }
     if (kTrain && g == 0) *save_rstd = rstd;
 }
@@ -219,8 +216,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             load_bias16(small, g, acc);
             layer_wide<kStagesL0>(pipe, acc, act);
             layer_norm_relu<kTrain>(small, g, acc, act,
-                                    kTrain ? ws + ka.save.xhat[0] + tile * 4096 + lane * 4 : nullptr,
-                                    kTrain ? ws + ka.save.x[0] + sp * kHidden + 4 * g : nullptr,
+                                    kTrain ? ws + ka.save.xhat[0] + sp * kHidden + 4 * g : nullptr,
                                     kTrain ? ws + ka.save.rstd[0] + sp : nullptr);
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
@@ -229,8 +225,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 load_bias16(small_l, g, acc);
                 layer_wide<kStagesHidden>(pipe, acc, act);
                 layer_norm_relu<kTrain>(small_l, g, acc, act,
-                                        kTrain ? ws + ka.save.xhat[L] + tile * 4096 + lane * 4 : nullptr,
-                                        kTrain ? ws + ka.save.x[L] + sp * kHidden + 4 * g : nullptr,
+                                        kTrain ? ws + ka.save.xhat[L] + sp * kHidden + 4 * g : nullptr,
                                         kTrain ? ws + ka.save.rstd[L] + sp : nullptr);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(handle):
     # packed image = 74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB
     assert handle.nerf_hip_packed_bytes() == 74 * 16384 + 3904 * 4 + 68 * 16384
     assert handle.nerf_hip_grad_elements() == 304438
-    assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 4073 * 4
+    assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 2793 * 4
     assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
 
 
