@@ -27,8 +27,190 @@ struct KernelArgs {
 
 typedef WeightPipe<kNumStages> FwdPipe;
 
-// Layer 5 (256 -> 64 padded): 4 stages, each 4 k-groups x 4 out tiles.
-__device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&acc)[4], const float (&act)[64]) {
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(256, eps 1e-5, affine, biased variance) + ReLU, fused INTO the MFMA loops around it.
+//
+// A sample's 256 features sit in 64 registers of each of the 4 lanes {j, j+16, j+32, j+48}; the
+// accumulator tile T (f32x4) of a layer is, after normalisation, the B operand of k-group T of the
+// next layer.  So the normalisation is deferred and applied in place, tile by tile, one stage
+// ahead of the stage that consumes the tile, and the moments are accumulated tile pair by tile
+// pair during the layer's last stage, one MFMA group behind the group that finishes the pair:
+// both passes issue in the shadow of MFMAs (an MFMA leaves ~6 VALU issue slots) instead of in a
+// VALU-only phase between two layers.  What stays exposed per layer: the moments of the last tile
+// pair, two cross-lane-group sums, the rsqrt, and the normalisation of tile 0.
+// ---------------------------------------------------------------------------------------------
+struct LazyNorm {
+    float rstd, shift;          // x_hat = fma(x, rstd, shift), shift = -mean * rstd
+    const f32x4* gam;           // this lane group's gamma / beta in LDS: tile T at [T]
+    const f32x4* bet;
+    float* save_row;            // training: this lane's x_hat row (tile T at + 16 T), else unused
+};
+
+struct Moments {
+    float s, q;
+    __device__ __forceinline__ void add(const f32x4& v) {
+#ifdef NERF_ABL_LN
+        return;
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s += v[r];
+            q = __builtin_fmaf(v[r], v[r], q);
+        }
+    }
+};
+
+template <bool kTrain>
+__device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T, const f32x4& ga,
+                                               const f32x4& be) {
+    f32x4 xh;
+#ifdef NERF_ABL_LN           /* timing experiment only: ReLU without the normalisation */
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaxf(x[r], 0.f);
+    return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xh[r] = __builtin_fmaf(x[r], n.rstd, n.shift);
+        x[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
+    }
+    if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
+}
+template <bool kTrain>
+__device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T) {
+    normalize_tile<kTrain>(x, n, T, n.gam[T], n.bet[T]);
+}
+
+// "1 MFMA, then `valu` VALU instructions", 7 times: spreads a region's VALU work over the gaps of
+// its 7 MFMAs (left alone, the scheduler parks it behind the last MFMA)
+template <int kValu>
+__device__ __forceinline__ void interleave_7() {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);    // VALU
+    }
+}
+
+// Moments -> the deferred normalisation of `raw` (the layer's finished accumulators).
+// var = E[x^2] - mean^2 cancels when |mean| >> std, so whenever the mean carries more than 3/4 of
+// the second moment in ANY sample of the wave, the exact two-pass variance is taken instead
+// (wave-uniform branch; pre-LayerNorm activations of this network have |mean| well below std, so
+// it is cold).  1/sqrt: hardware estimate (1 ulp) + one Newton step.
+template <bool kTrain>
+__device__ __forceinline__ LazyNorm finish_moments(const Moments& m, const f32x4 (&raw)[16],
+                                                   const float* small_l, int g, float* save_row,
+                                                   float* save_rstd) {
+    const float mean = group_sum(m.s) * (1.0f / 256.0f);
+    const float ex2 = group_sum(m.q) * (1.0f / 256.0f);
+    float var = ex2 - mean * mean;
+    if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = raw[T][r] - mean;
+                v = __builtin_fmaf(d, d, v);
+            }
+        }
+        var = group_sum(v) * (1.0f / 256.0f);
+    }
+    const float ve = var + 1e-5f;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
+    if (kTrain && g == 0) *save_rstd = rstd;
+    LazyNorm n;
+    n.rstd = rstd;
+    n.shift = -mean * rstd;
+    n.gam = (const f32x4*)(small_l + kHidden) + g * 16;
+    n.bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
+    n.save_row = save_row;
+    return n;
+}
+
+__device__ __forceinline__ void load_bias16(const float* small_l, int g, f32x4 (&acc)[16]) {
+    const f32x4* b = (const f32x4*)small_l + g * 16;
+#pragma unroll
+    for (int T = 0; T < 16; ++T) acc[T] = b[T];
+}
+
+// One 16-out-tile layer: out += W . in over KT k-groups (the MFMA software pipeline of
+// nerf_device.h: layer_wide), with `in` normalised lazily (kNormIn) and, in the last stage, the
+// moments of `out` gathered and `out` copied back into `in` (also in the MFMA shadow): every
+// layer then runs in -> out on the SAME two register tiles, so the four hidden layers share one
+// instance of this code (two ping-ponged instances overflowed the instruction cache: +2 %).
+template <int KT, bool kNormIn, bool kTrain>
+__device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
+                                            const LazyNorm& norm, Moments& mom) {
+    if (kNormIn) normalize_tile<kTrain>(in[0], norm, 0);
+    mom.s = mom.q = 0.f;
+    f32x4 a[2][2];
+    f32x4 ga, be;               // gamma / beta of the tile being normalised next
+    __builtin_amdgcn_s_setprio(0);
+    const f32x4* st = pipe.open_stage();
+    a[0][0] = st[0];
+    a[0][1] = st[64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const float b0 = in[t].x, b1 = in[t].y, b2 = in[t].z, b3 = in[t].w;
+#pragma unroll
+        for (int tp = 0; tp < 8; ++tp) {
+            const int cur = tp & 1, nxt = cur ^ 1;
+            const f32x4 a0 = a[cur][0], a1 = a[cur][1];
+            out[2 * tp] = mfma4(a0.x, b0, out[2 * tp]);
+            __builtin_amdgcn_sched_barrier(0);   // the wait for this group's operands is above this line
+            if (tp < 7) {
+                a[nxt][0] = st[(2 * tp + 2) * 64];
+                a[nxt][1] = st[(2 * tp + 3) * 64];
+                if (kNormIn && tp == 0 && t + 1 < KT) {      // a whole group ahead of their use
+                    ga = norm.gam[t + 1];
+                    be = norm.bet[t + 1];
+                }
+            } else if (t + 1 < KT) {
+                st = pipe.open_stage();
+                a[nxt][0] = st[0];
+                a[nxt][1] = st[64];
+                pipe.prefetch_next();
+            }
+            __builtin_amdgcn_sched_barrier(0);   // reads stay HERE (the scheduler would sink them)
+            out[2 * tp + 1] = mfma4(a1.x, b0, out[2 * tp + 1]);
+            out[2 * tp] = mfma4(a0.y, b1, out[2 * tp]);
+            out[2 * tp + 1] = mfma4(a1.y, b1, out[2 * tp + 1]);
+            out[2 * tp] = mfma4(a0.z, b2, out[2 * tp]);
+            out[2 * tp + 1] = mfma4(a1.z, b2, out[2 * tp + 1]);
+            out[2 * tp] = mfma4(a0.w, b3, out[2 * tp]);
+            out[2 * tp + 1] = mfma4(a1.w, b3, out[2 * tp + 1]);
+            // VALU riding in this group's MFMA shadow (same scheduling region as the 7 MFMAs):
+            if (kNormIn && tp == 1 && t + 1 < KT) {
+                normalize_tile<kTrain>(in[t + 1], norm, t + 1, ga, be);
+                interleave_7<2>();
+            }
+            if (t == KT - 1 && tp >= 1) {         // tile pair finished one group ago
+                mom.add(out[2 * tp - 2]);
+                mom.add(out[2 * tp - 1]);
+                in[2 * tp - 2] = out[2 * tp - 2];
+                in[2 * tp - 1] = out[2 * tp - 1];
+                interleave_7<4>();
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep groups apart (else reads re-issue just in time)
+        }
+    }
+    mom.add(out[14]);
+    mom.add(out[15]);
+    in[14] = out[14];
+    in[15] = out[15];
+    __builtin_amdgcn_s_setprio(2);
+}
+
+// Layer 5 (256 -> 64 padded): 4 stages, each 4 k-groups x 4 out tiles; its input is normalised
+// lazily like in layer_fused, one k-group (16 MFMAs) ahead.
+template <bool kTrain>
+__device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
+                                          const LazyNorm& norm) {
+    normalize_tile<kTrain>(in[0], norm, 0);
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int s = 0; s < kStagesL5; ++s) {
         const f32x4* st = pipe.open_stage();
@@ -45,96 +227,27 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&acc)[4], const 
             }
             const f32x4 a0 = q[(tl & 1) * 4 + 0], a1 = q[(tl & 1) * 4 + 1], a2 = q[(tl & 1) * 4 + 2],
                         a3 = q[(tl & 1) * 4 + 3];
-            acc[0] = mfma4(a0.x, act[4 * t], acc[0]);
-            acc[1] = mfma4(a1.x, act[4 * t], acc[1]);
-            acc[2] = mfma4(a2.x, act[4 * t], acc[2]);
-            acc[3] = mfma4(a3.x, act[4 * t], acc[3]);
-            acc[0] = mfma4(a0.y, act[4 * t + 1], acc[0]);
-            acc[1] = mfma4(a1.y, act[4 * t + 1], acc[1]);
-            acc[2] = mfma4(a2.y, act[4 * t + 1], acc[2]);
-            acc[3] = mfma4(a3.y, act[4 * t + 1], acc[3]);
-            acc[0] = mfma4(a0.z, act[4 * t + 2], acc[0]);
-            acc[1] = mfma4(a1.z, act[4 * t + 2], acc[1]);
-            acc[2] = mfma4(a2.z, act[4 * t + 2], acc[2]);
-            acc[3] = mfma4(a3.z, act[4 * t + 2], acc[3]);
-            acc[0] = mfma4(a0.w, act[4 * t + 3], acc[0]);
-            acc[1] = mfma4(a1.w, act[4 * t + 3], acc[1]);
-            acc[2] = mfma4(a2.w, act[4 * t + 3], acc[2]);
-            acc[3] = mfma4(a3.w, act[4 * t + 3], acc[3]);
+            const f32x4 b = in[t];
+            acc[0] = mfma4(a0.x, b.x, acc[0]);
+            acc[1] = mfma4(a1.x, b.x, acc[1]);
+            acc[2] = mfma4(a2.x, b.x, acc[2]);
+            acc[3] = mfma4(a3.x, b.x, acc[3]);
+            acc[0] = mfma4(a0.y, b.y, acc[0]);
+            acc[1] = mfma4(a1.y, b.y, acc[1]);
+            acc[2] = mfma4(a2.y, b.y, acc[2]);
+            acc[3] = mfma4(a3.y, b.y, acc[3]);
+            acc[0] = mfma4(a0.z, b.z, acc[0]);
+            acc[1] = mfma4(a1.z, b.z, acc[1]);
+            acc[2] = mfma4(a2.z, b.z, acc[2]);
+            acc[3] = mfma4(a3.z, b.z, acc[3]);
+            acc[0] = mfma4(a0.w, b.w, acc[0]);
+            acc[1] = mfma4(a1.w, b.w, acc[1]);
+            acc[2] = mfma4(a2.w, b.w, acc[2]);
+            acc[3] = mfma4(a3.w, b.w, acc[3]);
+            if (t + 1 < 16) normalize_tile<kTrain>(in[t + 1], norm, t + 1);
         }
     }
-}
-
-// LayerNorm(256, eps 1e-5, affine, biased variance) + ReLU on the accumulator tile, result
-// written as the next layer's B operands.  A sample's 256 features sit in 64 registers of
-// each of the 4 lanes {j, j+16, j+32, j+48}.  Training also saves x_hat (row order: the backward's
-// LayerNorm and, through the affine + ReLU, its weight-gradient operand) and 1/std.
-template <bool kTrain>
-__device__ __forceinline__ void layer_norm_relu(const float* small_l, int g, const f32x4 (&acc)[16],
-                                                float (&act)[64], float* save_xhat_row,
-                                                float* save_rstd) {
-#ifdef NERF_ABL_LN           /* timing experiment only: ReLU without the normalisation */
-#pragma unroll
-    for (int T = 0; T < 16; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
-    return;
-#endif
-    // One pass: sum and sum of squares together (128 VALU instead of 192).  var = E[x^2] - mean^2
-    // cancels when |mean| >> std, so whenever the mean carries more than 3/4 of the second moment
-    // in ANY sample of the wave, the exact two-pass variance is taken instead (wave-uniform branch;
-    // pre-LayerNorm activations of this network have |mean| well below std, so it is cold).
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s += acc[T][r];
-            q = __builtin_fmaf(acc[T][r], acc[T][r], q);
-        }
-    }
-    s = group_sum(s);
-    q = group_sum(q);
-    const float mean = s * (1.0f / 256.0f);
-    const float ex2 = q * (1.0f / 256.0f);
-    float var = ex2 - mean * mean;
-    if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
-        float v = 0.f;
-#pragma unroll
-        for (int T = 0; T < 16; ++T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = acc[T][r] - mean;
-                v = __builtin_fmaf(d, d, v);
-            }
-        }
-        var = group_sum(v) * (1.0f / 256.0f);
-    }
-    // 1/sqrt: hardware estimate (1 ulp) + one Newton step, instead of IEEE sqrt followed by divide
-    const float ve = var + 1e-5f;
-    float rstd = __builtin_amdgcn_rsqf(ve);
-    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-    const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
-    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        const f32x4 ga = gam[T], be = bet[T];
-        f32x4 xh, xo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            xh[r] = (acc[T][r] - mean) * rstd;
-            xo[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
-            act[4 * T + r] = xo[r];
-        }
-        if (kTrain) *(f32x4*)(save_xhat_row + T * 16) = xh;
-    }
-    if (kTrain && g == 0) *save_rstd = rstd;
-}
-
-__device__ __forceinline__ void load_bias16(const float* small_l, int g, f32x4 (&acc)[16]) {
-    const f32x4* b = (const f32x4*)small_l + g * 16;
-#pragma unroll
-    for (int T = 0; T < 16; ++T) acc[T] = b[T];
+    __builtin_amdgcn_s_setprio(2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,8 +286,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     }
 #endif
 
-    float act[64];
-    f32x4 acc[16];
+    f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators
     float* const ws = a.train_workspace;
 
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
@@ -204,29 +316,35 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 const Gaussian gn = frustum(ray, t1, t2, a.base_radius_sq);
                 dist = s == P - 1 ? 1e10f : mean_distance(gs, gn);
             }
-            encode(gs, g, act);
+            {
+                float feat[64];
+                encode(gs, g, feat);
+#pragma unroll
+                for (int t = 0; t < kStagesL0; ++t)
+                    X[t] = f32x4{feat[4 * t], feat[4 * t + 1], feat[4 * t + 2], feat[4 * t + 3]};
+            }
             if (kTrain) {
                 float* hrow = ws + ka.save.h + sp * kEncIn + 4 * g;
 #pragma unroll
-                for (int t = 0; t < kStagesL0; ++t)
-                    *(f32x4*)(hrow + 16 * t) = f32x4{act[4 * t], act[4 * t + 1], act[4 * t + 2], act[4 * t + 3]};
+                for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
+            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;     // + ka.save.xhat[L]
+            float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
             // ---- layer 0: 96 -> 256 ----
-            load_bias16(small, g, acc);
-            layer_wide<kStagesL0>(pipe, acc, act);
-            layer_norm_relu<kTrain>(small, g, acc, act,
-                                    kTrain ? ws + ka.save.xhat[0] + sp * kHidden + 4 * g : nullptr,
-                                    kTrain ? ws + ka.save.rstd[0] + sp : nullptr);
+            Moments mom;
+            LazyNorm norm;
+            load_bias16(small, g, Y);
+            layer_fused<kStagesL0, false, kTrain>(pipe, X, Y, norm, mom);
+            norm = finish_moments<kTrain>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0]);
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
             for (int L = 1; L <= 4; ++L) {
                 const float* small_l = small + L * kSmallPerLayer;
-                load_bias16(small_l, g, acc);
-                layer_wide<kStagesHidden>(pipe, acc, act);
-                layer_norm_relu<kTrain>(small_l, g, acc, act,
-                                        kTrain ? ws + ka.save.xhat[L] + sp * kHidden + 4 * g : nullptr,
-                                        kTrain ? ws + ka.save.rstd[L] + sp : nullptr);
+                load_bias16(small_l, g, Y);
+                layer_fused<kStagesHidden, true, kTrain>(pipe, X, Y, norm, mom);
+                norm = finish_moments<kTrain>(mom, X, small_l, g, xrow + ka.save.xhat[L],
+                                              rstd_p + ka.save.rstd[L]);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----
             f32x4 out[4];
@@ -235,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = b[T];
             }
-            layer_out(pipe, out, act);
+            layer_out<kTrain>(pipe, X, out, norm);
             if (kTrain) {
                 float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
 #pragma unroll
