@@ -135,3 +135,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", ""), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU/eager fallback: without the HIP library the package refuses to render."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['NERF_HIP_LIB'] = %r\n"
+            "from nerf_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept RuntimeError as e:\n    print('RAISED', 'no CPU' in str(e) or 'missing' in str(e))\n"
+            % (ROOT, str(tmp_path / "absent.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
