@@ -100,15 +100,16 @@ struct WeightPipe {
     }
 
     // Top of a stage: this wave's DMA pieces of the stage have landed (the 4 youngest = the next
-    // stage may still fly; any other younger vector-memory op only makes the wait conservative),
-    // every wave has passed the barrier, so (a) all 16 pieces are visible and (b) every wave has
-    // issued its last reads of the slot the next issue() overwrites (an LDS-DMA write lands a
-    // global-memory round trip after its issue, long after those already-queued LDS reads).
+    // stage may still fly; any other younger vector-memory op only makes the wait conservative)
+    // and its LDS reads have all returned (lgkmcnt(0): free in the MFMA loops, whose hand-over
+    // sits behind the wait that retired the last reads of the old stage); every wave has passed
+    // the barrier, so (a) all 16 pieces are visible and (b) every wave has RETIRED its reads of the
+    // slot the next issue() overwrites: write-after-read safe without any timing argument.
     // The caller reads its first operands, THEN calls issue(): the reads' latency hides under the
     // previous stage's trailing MFMAs instead of behind the DMA address arithmetic.
     __device__ __forceinline__ const f32x4* open_stage() {
 #ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 #endif
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
