@@ -134,43 +134,21 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     }
 }
 
-__global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Compositing backward: one wave per padded ray slot, chunks walked last to first (the
+// transmittance gradient is a suffix sum along the ray); writes dL/d(out) of every sample row-major
+// ([sp][64]: the B operand of the data-gradient chain and the dY of layer 5's weight gradient).
+__global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs ba) {
     const NerfHipRenderArgs& a = ba.a;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int P = ba.intervals;
     const int chunks = ba.chunks;
     float* const ws = a.train_workspace;
-    float* const gb = (float*)(smem + kSmallLdsBytes + kRing * kStageBytes);
-
-    {
-        const float* small_g = a.packed + kBlobFloats;
-        float* small_l = (float*)smem;
-        for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
-        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
-    }
-    const float* small = (const float*)smem;
-
-    BwdPipe pipe;
-    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, wave, lane);
-    pipe.issue();
-    pipe.issue();
-    __syncthreads();
-
-    float act[64];
-    f32x4 acc[16];
-    GammaBetaTurn turn;
-    turn.dst = gb + 16 * j + 4 * g;
-    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
-    turn.wave = wave;
-
-    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
-        const int64_t slot = grp * kWavesPerWg + wave;
-        int64_t local = slot;
-        const bool ray_ok = local < a.n_rays;
-        if (!ray_ok) local = a.n_rays - 1;
+    const int64_t slot = (int64_t)blockIdx.x * kWavesPerWg + wave;
+    if (slot * chunks * 16 >= ba.L.mp) return;
+    int64_t local = slot;
+    const bool ray_ok = local < a.n_rays;
+    if (!ray_ok) local = a.n_rays - 1;
 
         // upstream gradients of this ray
         const float g0 = ray_ok ? ba.d_rgb[local * 3 + 0] : 0.f;
@@ -274,6 +252,55 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
                 float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
 #pragma unroll
                 for (int T = 0; T < 4; ++T) *(f32x4*)(drow + T * 16) = dout[T];
+            }
+
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int P = ba.intervals;
+    const int chunks = ba.chunks;
+    float* const ws = a.train_workspace;
+    float* const gb = (float*)(smem + kSmallLdsBytes + kRing * kStageBytes);
+
+    {
+        const float* small_g = a.packed + kBlobFloats;
+        float* small_l = (float*)smem;
+        for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
+        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+    }
+    const float* small = (const float*)smem;
+
+    BwdPipe pipe;
+    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    // one (padded ray, chunk) item per wave: dL/d(out) of every sample was written by
+    // nerf_composite_bwd_kernel (the suffix sum along the ray lives there), so the chunks of a ray
+    // are independent here and a small batch still fills the chip
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
+        {
+            const int64_t sp = tile * 16 + j;
+            f32x4 dout[4];
+            {
+                const float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
             }
 
             // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
@@ -567,8 +594,9 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.d_seg = args->d_seg;
     ba.intervals = a.num_samples - 1;
     ba.chunks = (ba.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
-    ba.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
     ba.L = make_train_layout(a.n_rays, ba.chunks);
+    ba.groups = ba.L.mp / 16 / kWavesPerWg;                 // (padded ray, chunk) items / 4 waves
+    const int64_t slots = ba.L.mp / 16 / ba.chunks;         // padded rays
     ba.grad = args->grad;
     ba.n_tiles = ba.L.mp / kKs;
     ba.splits = choose_splits(ba.n_tiles);
@@ -594,6 +622,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.data_grid = (int)grid;
 
     float* ws = a.train_workspace;
+    hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
+                       dim3(256), 0, st, ba);
     hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 6), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
     const int threads = 256;

@@ -409,5 +409,112 @@ __device__ __forceinline__ float mean_distance(const Gaussian& a, const Gaussian
     return __builtin_sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// compositing of one 16-sample chunk (nerf/model.py:438-469, :660-663), shared by the fused
+// inference kernel and the stand-alone compositing kernel of the training path
+// ---------------------------------------------------------------------------------------------
+struct RayAccum {
+    float carry;                // prod (alpha_i + 1e-10) over the finished chunks of the ray
+    float rgb0, rgb1, rgb2;
+    // running log-sum-exp over the ray's samples of ONE output slot per lane: lane (j, g) owns
+    // slot i = j of its lane group, i.e. output n = 16 (j >> 2) + 4 g + (j & 3)
+    float seg_m, seg_s;
+    __device__ __forceinline__ void reset() {
+        carry = 1.0f;
+        rgb0 = rgb1 = rgb2 = 0.f;
+        seg_m = -__builtin_inff();
+        seg_s = 0.f;
+    }
+};
+
+// out[T][r] = padded network output n = 16 T + 4 g + r of sample s = 16 c + j (accumulator
+// layout); returns the compositing weight of the sample.  `comp` (training): where this sample's
+// (alpha, T_exclusive, dist, density + noise) goes.
+template <bool kSave>
+__device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int P, int64_t local, int s,
+                                                 bool ok, int lane, const f32x4 (&out)[4], float dist,
+                                                 RayAccum& acc, float* comp) {
+#pragma clang fp contract(off)
+    const int j = lane & 15, g = lane >> 4;
+    float dens = __shfl(out[0].x, j);
+    if (a.noise != nullptr) {
+        if (ok) dens = dens + a.noise[local * P + s] * a.density_noise_std;
+    } else if (a.rng_mode & 2) {
+        dens = dens + nerf_rng::normal(a.rng_seed, a.rng_offset, (uint64_t)(a.ray_begin + local),
+                                       (uint32_t)s, 1u) * a.density_noise_std;
+    }
+    const float alpha = ok ? expf(-__builtin_fmaxf(dens, 0.f) * dist) : 1.0f;
+    const float prod = row_prefix_prod(ok ? alpha + 1e-10f : 1.0f);
+    const float t_excl = acc.carry * row_shift_up(1.0f, prod);
+    const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
+    acc.carry = acc.carry * __shfl(prod, (lane & 48) | 15);
+    if (kSave && g == 0) *(f32x4*)comp = f32x4{alpha, t_excl, dist, dens};
+
+    // RGB: valid on lane group 0, harmless elsewhere
+    const float cr = w * (1.0f / (1.0f + expf(-out[0].y)));
+    const float cg = w * (1.0f / (1.0f + expf(-out[0].z)));
+    const float cb = w * (1.0f / (1.0f + expf(-out[0].w)));
+    acc.rgb0 += row_sum(cr);
+    acc.rgb1 += row_sum(cg);
+    acc.rgb2 += row_sum(cb);
+
+#ifdef NERF_ABL_COMP         /* timing experiment only: no segmentation compositing */
+    if (false) {
+#else
+    if (a.seg != nullptr) {
+#endif
+        // log_softmax over the 50 class logits of this sample
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
+        m = group_max(m);
+        float z = 0.f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (is_seg_slot(T, g, r)) z += exp_fast(out[T][r] - m);
+        z = group_sum(z);
+        const float logz = logf(z);
+        const float lw = logf(w + 1e-10f);
+        // log-sum-exp over the 16 samples of the chunk per slot (row reductions), then merged
+        // into the owning lane's running (max, sum)
+        float cm = 0.f, cs = 0.f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = ok ? lw + ((out[T][r] - m) - logz) : -__builtin_inff();
+                const float vm = row_max(v);              // lane 0 of a chunk is always valid
+                const float ve = row_sum(exp_fast(v - vm));
+                if (j == 4 * T + r) {
+                    cm = vm;
+                    cs = ve;
+                }
+            }
+        const float nm = __builtin_fmaxf(acc.seg_m, cm);
+        acc.seg_s = acc.seg_s * exp_fast(acc.seg_m - nm) + cs * exp_fast(cm - nm);
+        acc.seg_m = nm;
+    }
+    return w;
+}
+
+// one coalesced store instruction per output row
+__device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t local, bool ray_ok, int lane,
+                                          const RayAccum& acc) {
+    if (ray_ok && lane < 3) a.rgb[local * 3 + lane] = lane == 0 ? acc.rgb0 : (lane == 1 ? acc.rgb1 : acc.rgb2);
+    if (a.seg != nullptr) {
+        // the wave's 64 lanes cover n = 0..63 once: the 50 class values leave in one store
+        const int j = lane & 15, g = lane >> 4;
+        const float mine = acc.seg_m + logf(acc.seg_s);
+        const int n = 16 * (j >> 2) + 4 * g + (j & 3);
+        if (ray_ok && n >= 4 && n < kOut) a.seg[local * kSegClasses + (n - 4)] = mine;
+    }
+}
+
 }  // namespace nerf_device
 #endif

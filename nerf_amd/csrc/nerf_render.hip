@@ -289,20 +289,23 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators
     float* const ws = a.train_workspace;
 
+    // Inference: a wave owns a ray, walks its chunks in order and composites as it goes.
+    // Training: compositing is a kernel of its own (nerf_composite_fwd_kernel), so the unit of
+    // work here is one (ray, chunk) item per wave — a 512-ray batch then fills all 2,048 waves
+    // instead of 512 of them — and the network outputs / distances are saved for it.
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
-        const int64_t slot = grp * kWavesPerWg + wave;      // padded ray slot (workspace rows)
+        const int64_t unit = grp * kWavesPerWg + wave;
+        const int64_t slot = kTrain ? unit / chunks : unit;      // padded ray slot (workspace rows)
         int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
         const Ray ray = load_ray(a, local);
+        RayAccum racc;
+        racc.reset();
 
-        float carry = 1.0f;                     // prod (alpha_i + 1e-10) over finished chunks
-        float rgb0 = 0.f, rgb1 = 0.f, rgb2 = 0.f;
-        // running log-sum-exp over the ray's samples of ONE output slot per lane: lane (j, g)
-        // owns slot i = j of its lane group, i.e. output n = 16 (j >> 2) + 4 g + (j & 3)
-        float seg_m = -__builtin_inff(), seg_s = 0.f;
-
-        for (int c = 0; c < chunks; ++c) {
+        const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
+        const int c_end = kTrain ? c_begin + 1 : chunks;
+        for (int c = c_begin; c < c_end; ++c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = s < P;
             const int64_t tile = slot * chunks + c;         // chunk index in the workspace
@@ -360,112 +363,67 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 for (int T = 0; T < 4; ++T) *(f32x4*)(otile + T * 256) = out[T];
             }
 
+            if (kTrain) {
+                if (g == 0) *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{0.f, 0.f, dist, 0.f};
+                continue;
+            }
+
             // ---- compositing (nerf/model.py:438-469, :660-663) ----
-            {
-#pragma clang fp contract(off)
-                float dens = __shfl(out[0].x, j);
-                if (a.noise != nullptr) {
-                    if (ok) dens = dens + a.noise[local * P + s] * a.density_noise_std;
-                } else if (a.rng_mode & 2) {
-                    dens = dens + nerf_rng::normal(a.rng_seed, a.rng_offset,
-                                                   (uint64_t)(a.ray_begin + local), (uint32_t)s, 1u)
-                                      * a.density_noise_std;
-                }
-                const float alpha = ok ? expf(-__builtin_fmaxf(dens, 0.f) * dist) : 1.0f;
-                const float prod = row_prefix_prod(ok ? alpha + 1e-10f : 1.0f);
-                const float t_excl = carry * row_shift_up(1.0f, prod);
-                const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
-                carry = carry * __shfl(prod, (lane & 48) | 15);
-                if (kTrain && g == 0)
-                    *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{alpha, t_excl, dist, dens};
-
-                // RGB: valid on lane group 0, harmless elsewhere
-                const float cr = w * (1.0f / (1.0f + expf(-out[0].y)));
-                const float cg = w * (1.0f / (1.0f + expf(-out[0].z)));
-                const float cb = w * (1.0f / (1.0f + expf(-out[0].w)));
-                rgb0 += row_sum(cr);
-                rgb1 += row_sum(cg);
-                rgb2 += row_sum(cb);
-
-#ifdef NERF_ABL_COMP         /* timing experiment only: no segmentation compositing */
-                if (false) {
-#else
-                if (a.seg != nullptr) {
-#endif
-                    // log_softmax over the 50 class logits of this sample
-                    float m = -__builtin_inff();
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
-                    m = group_max(m);
-                    float z = 0.f;
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) z += exp_fast(out[T][r] - m);
-                    z = group_sum(z);
-                    const float logz = logf(z);
-                    const float lw = logf(w + 1e-10f);
-                    // log-sum-exp over the 16 samples of the chunk per slot (row reductions), then
-                    // merged into the owning lane's running (max, sum)
-                    float cm = 0.f, cs = 0.f;
+            const float w = composite_chunk<false>(a, P, local, s, ok, lane, out, dist, racc, nullptr);
+            // optional per-sample outputs (NeRF.forward, nerf/model.py:553-594)
+            if (ray_ok && ok) {
+                const int64_t smp = local * P + s;
+                if (a.out_raw != nullptr) {
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = ok ? lw + ((out[T][r] - m) - logz) : -__builtin_inff();
-                            const float vm = row_max(v);              // lane 0 of a chunk is always valid
-                            const float ve = row_sum(exp_fast(v - vm));
-                            if (j == 4 * T + r) {
-                                cm = vm;
-                                cs = ve;
-                            }
+                            const int n = 16 * T + 4 * g + r;
+                            if (n < kOut) a.out_raw[smp * kOut + n] = out[T][r];
                         }
-                    const float nm = __builtin_fmaxf(seg_m, cm);
-                    seg_s = seg_s * exp_fast(seg_m - nm) + cs * exp_fast(cm - nm);
-                    seg_m = nm;
                 }
-
-                // optional per-sample outputs (NeRF.forward, nerf/model.py:553-594)
-                if (ray_ok && ok) {
-                    const int64_t smp = local * P + s;
-                    if (a.out_raw != nullptr) {
-#pragma unroll
-                        for (int T = 0; T < 4; ++T)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int n = 16 * T + 4 * g + r;
-                                if (n < kOut) a.out_raw[smp * kOut + n] = out[T][r];
-                            }
+                if (g == 0) {
+                    if (a.out_mean != nullptr) {
+                        a.out_mean[smp * 3 + 0] = gs.mean[0];
+                        a.out_mean[smp * 3 + 1] = gs.mean[1];
+                        a.out_mean[smp * 3 + 2] = gs.mean[2];
                     }
-                    if (g == 0) {
-                        if (a.out_mean != nullptr) {
-                            a.out_mean[smp * 3 + 0] = gs.mean[0];
-                            a.out_mean[smp * 3 + 1] = gs.mean[1];
-                            a.out_mean[smp * 3 + 2] = gs.mean[2];
-                        }
-                        if (a.out_weights != nullptr) a.out_weights[smp] = w;
-                    }
+                    if (a.out_weights != nullptr) a.out_weights[smp] = w;
                 }
             }
         }
-
-        // ---- ray epilogue: one coalesced store instruction per output row ----
-        if (ray_ok && lane < 3) {
-            const float v = lane == 0 ? rgb0 : (lane == 1 ? rgb1 : rgb2);
-            a.rgb[local * 3 + lane] = v;
-        }
-        if (a.seg != nullptr) {
-            // the wave's 64 lanes cover n = 0..63 once: the 50 class values leave in one store
-            const float mine = seg_m + logf(seg_s);
-            const int n = 16 * (j >> 2) + 4 * g + (j & 3);
-            if (ray_ok && n >= 4 && n < kOut) a.seg[local * kSegClasses + (n - 4)] = mine;
-        }
+        if (!kTrain) store_ray(a, local, ray_ok, lane, racc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// Compositing of the training forward: one wave per ray over the saved network outputs.
+__global__ __launch_bounds__(256) void nerf_composite_fwd_kernel(const KernelArgs ka) {
+    const NerfHipRenderArgs& a = ka.a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15;
+    const int64_t local = (int64_t)blockIdx.x * kWavesPerWg + wave;
+    if (local >= a.n_rays) return;
+    const int P = ka.intervals;
+    float* const ws = a.train_workspace;
+    RayAccum racc;
+    racc.reset();
+    for (int c = 0; c < ka.chunks; ++c) {
+        const int s = c * kSamplesPerWave + j;
+        const bool ok = s < P;
+        const int64_t tile = local * ka.chunks + c;
+        const int64_t sp = tile * 16 + j;
+        f32x4 out[4];
+        const float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
+        float* comp = ws + ka.save.comp + sp * 4;
+        const float dist = comp[2];
+        const float w = composite_chunk<true>(a, P, local, s, ok, lane, out, dist, racc, comp);
+        if (a.out_weights != nullptr && ok && lane < 16) a.out_weights[local * P + s] = w;
+    }
+    store_ray(a, local, true, lane, racc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,9 +548,12 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.a = a;
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
-    ka.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
     ka.save = make_train_layout(a.n_rays, ka.chunks);
     const bool train = a.train_workspace != nullptr;
+    if (train && (a.out_raw != nullptr || a.out_mean != nullptr))
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean are not produced by the training forward");
+    // inference: one ray per wave; training: one (padded ray, chunk) item per wave
+    ka.groups = train ? ka.save.mp / 16 / kWavesPerWg : (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
 
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
@@ -611,9 +572,11 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    if (train)
+    if (train) {
         hipLaunchKernelGGL(nerf_render_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
-    else
+        const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+        hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
+    } else
         hipLaunchKernelGGL(nerf_render_fwd_kernel<false>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
     nerf_common::Timing::after(st);
