@@ -133,10 +133,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    backend = None
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:                                      # RCCL over xGMI; only barriers + one scalar reduce use it
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            backend = "nccl"
+        except Exception as exc:                  # keep the measurement alive if RCCL cannot come up
+            print(f"[bench] nccl init failed ({exc}); falling back to gloo for the barriers", file=sys.stderr)
+            dist.init_process_group("gloo")
+            backend = "gloo"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
 
@@ -183,7 +190,7 @@ def main():
     _lib.timing(False)
     assert torch.isfinite(out[0]).all()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -216,6 +223,7 @@ def main():
                 "frames": world if args.scaling == "weak" else 1,
                 "sharding": "one frame per GPU" if args.scaling == "weak" else "row blocks of one frame",
                 "collectives": "none",
+                "rendezvous_backend": backend,
             },
             "roofline": {
                 "bound": "mfma",
