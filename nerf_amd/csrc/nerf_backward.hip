@@ -357,18 +357,25 @@ typedef WgradShape<kHidden, kHidden, 4, 4> ShapeHid;       // waves 2x2: 4x4 til
 typedef WgradShape<kOutPad, kHidden, 2, 2> ShapeL5;        // waves: both out tiles, in tiles 2w..2w+1
 
 template <class Sh>
-__device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int64_t sample0,
-                                            char* buf, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < Sh::kPiecesPerWave; ++i) {
+__device__ __forceinline__ void wgrad_issue_piece(const float* dy, const float* x, int64_t sample0,
+                                                  char* buf, int wave, int lane, int i) {
+    {
         const int piece = wave * Sh::kPiecesPerWave + i;
         const int byte = piece * 1024;
         const char* src = byte < Sh::kDyBytes
                               ? (const char*)(dy + sample0 * Sh::kOutW) + byte
                               : (const char*)(x + sample0 * Sh::kInW) + (byte - Sh::kDyBytes);
+#ifndef NERF_EXP_WGRAD_NODMA     /* timing experiment only */
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
                                          (__attribute__((address_space(3))) void*)(buf + byte), 16, 0, 0);
+#endif
     }
+}
+template <class Sh>
+__device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int64_t sample0,
+                                            char* buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < Sh::kPiecesPerWave; ++i) wgrad_issue_piece<Sh>(dy, x, sample0, buf, wave, lane, i);
 }
 
 // `x` rows are the layer's input: the encoded features (layer 0, kAffine false) or the saved x_hat
@@ -414,16 +421,14 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
 
     if (nt > 0) wgrad_issue<Sh>(dy, x, tile_begin * kKs, smem, wave, lane);
     for (int64_t k = 0; k < nt; ++k) {
+        // The next tile's LDS-DMA pieces are issued ONE PER K-STEP inside this tile's MFMA loop (one
+        // wave per SIMD here: a burst of 16 back-to-back DMA issues would idle the matrix pipe for
+        // ~1,000 of the tile's 16,384 cycles).  So at this point only this tile's pieces can be in
+        // flight: vmcnt(0).
         char* cur = smem + (k & 1) * Sh::kTileBytes;
-        if (k + 1 < nt) {
-            wgrad_issue<Sh>(dy, x, (tile_begin + k + 1) * kKs, smem + ((k + 1) & 1) * Sh::kTileBytes,
-                            wave, lane);
-            if (Sh::kPiecesPerWave == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (Sh::kPiecesPerWave == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        char* nxt_buf = smem + ((k + 1) & 1) * Sh::kTileBytes;
+        const bool more = k + 1 < nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const float* dyt = (const float*)cur;
@@ -435,19 +440,25 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
 #pragma unroll
         for (int a = 0; a < Sh::kTo; ++a) af[0][a] = dyt[kk * Sh::kOutW + 32 * (out0 + a) + i];
 #pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = input(xt[kk * Sh::kInW + 32 * (in0 + b) + i], b);
+        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = xt[kk * Sh::kInW + 32 * (in0 + b) + i];
 #pragma unroll
         for (int step = 0; step < kKs / 2; ++step) {
             const int cur = step & 1, nxt = cur ^ 1;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bf[cur][0], acc[0][0], 0, 0, 0);
+            // affine + ReLU at USE time: applied at load time it would pull the LDS wait up to the
+            // reads and undo their one-k-step prefetch
+            float bv[Sh::kTi];
+#pragma unroll
+            for (int b = 0; b < Sh::kTi; ++b) bv[b] = input(bf[cur][b], b);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bv[0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (step < Sh::kPiecesPerWave && more)
+                wgrad_issue_piece<Sh>(dy, x, (tile_begin + k + 1) * kKs, nxt_buf, wave, lane, step);
             if (step + 1 < kKs / 2) {
                 const int srow = 2 * (step + 1) + kk;
 #pragma unroll
                 for (int a = 0; a < Sh::kTo; ++a) af[nxt][a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
 #pragma unroll
-                for (int b = 0; b < Sh::kTi; ++b)
-                    bf[nxt][b] = input(xt[srow * Sh::kInW + 32 * (in0 + b) + i], b);
+                for (int b = 0; b < Sh::kTi; ++b) bf[nxt][b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -455,8 +466,7 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
 #pragma unroll
                 for (int b = 0; b < Sh::kTi; ++b)
                     if (a + b > 0)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b],
-                                                                         0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bv[b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((int)threadIdx.x < Sh::kOutW) {       // bias gradient: column sums of dY
@@ -625,7 +635,11 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                        dim3(256), 0, st, ba);
     hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+#ifdef NERF_EXP_WGRAD_HID_ONLY   /* timing experiment: hidden layers only (wrong gradients) */
+    hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 4), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+#else
     hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 6), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+#endif
     const int threads = 256;
     hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((kGradElements + threads - 1) / threads), dim3(threads),
                        0, st, ba);
