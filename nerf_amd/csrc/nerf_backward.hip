@@ -263,8 +263,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int P = ba.intervals;
-    const int chunks = ba.chunks;
     float* const ws = a.train_workspace;
     float* const gb = (float*)(smem + kSmallLdsBytes + kRing * kStageBytes);
 
@@ -631,7 +629,6 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;
     ba.data_grid = (int)grid;
 
-    float* ws = a.train_workspace;
     hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                        dim3(256), 0, st, ba);
     hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);

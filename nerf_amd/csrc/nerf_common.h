@@ -68,18 +68,18 @@ struct Timing {
         }
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
-        hipEventRecord(e, st);
+        (void)hipEventRecord(e, st);
         pending() = e;
     }
     static void after(hipStream_t st) {
         if (pending() == nullptr) return;
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) {
-            hipEventDestroy(pending());
+            (void)hipEventDestroy(pending());
             pending() = nullptr;
             return;
         }
-        hipEventRecord(e, st);
+        (void)hipEventRecord(e, st);
         std::lock_guard<std::mutex> lk(mu());
         pairs().push_back(Pair{pending(), e});
         pending() = nullptr;
@@ -100,8 +100,8 @@ struct Timing {
         if (launches) *launches = n;
         if (reset) {
             for (auto& p : pairs()) {
-                hipEventDestroy(p.start);
-                hipEventDestroy(p.stop);
+                (void)hipEventDestroy(p.start);
+                (void)hipEventDestroy(p.stop);
             }
             pairs().clear();
         }
