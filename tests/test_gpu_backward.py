@@ -52,7 +52,7 @@ def test_training_step_vs_reference(dev, name, scale):
                                   noise=g["noise"].to(dev))
     assert pixels.requires_grad
     loss = ((pixels - g["target"].to(dev).unsqueeze(1)) ** 2).mean()
-    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6
     opt.zero_grad()
     loss.backward()
     exact = fp64_gradients(golden_params(scale), lambda p: O.training_loss(

@@ -93,7 +93,7 @@ def test_training_gradients(name, scale):
     p = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in golden_params(scale).items()}
     loss = O.training_loss(p, CFG, g["rays_o"], g["rays_d"], 64, g["target"], g["u"], g["noise"],
                            float(g["noise_std"]))
-    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6
     loss.backward()
     n_checked = 0
     for k, v in p.items():
