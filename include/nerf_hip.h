@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 1
+#define NERF_HIP_ABI_VERSION 2
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -39,6 +39,9 @@ extern "C" {
 #define NERF_HIP_ENC_INPUTS 96
 #define NERF_HIP_OUTPUTS 54
 #define NERF_HIP_NUM_PARAM_TENSORS 22
+
+#define NERF_HIP_PRECISION_FP32 0
+#define NERF_HIP_PRECISION_F16X3 1
 
 /* ABI version of the loaded library (NERF_HIP_ABI_VERSION at build time). */
 int nerf_hip_version(void);
@@ -98,6 +101,11 @@ typedef struct NerfHipRenderArgs {
     /* training: non-NULL makes the forward also save what the backward needs (activations,
      * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats      */
     float* train_workspace;
+    /* arithmetic of the MLP (inference only; the training forward takes FP32):
+     * FP32  = exact-fp32 MFMA, the reference's arithmetic (torch fp32, nerf/model.py:525-542);
+     * F16X3 = every fp32 operand split into an f16 pair, three f16 MFMAs per product with fp32
+     *         accumulation (~2^-22 relative per product; same 1e-4 RGB parity bar)            */
+    int32_t precision;
 } NerfHipRenderArgs;
 
 /* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional

@@ -8,8 +8,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (kernel experiments: scripts/ablate.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_PARAM_TENSORS = 22
+PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
 _f32p = ctypes.c_void_p
 
@@ -33,6 +34,7 @@ class RenderArgs(ctypes.Structure):
         ("rgb", _f32p), ("seg", _f32p),
         ("out_mean", _f32p), ("out_raw", _f32p), ("out_weights", _f32p),
         ("train_workspace", _f32p),
+        ("precision", ctypes.c_int32),
     ]
 
 

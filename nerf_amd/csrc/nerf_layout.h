@@ -48,7 +48,24 @@ constexpr int kSmallFloats = 5 * kSmallPerLayer + kOutPad;   // 3904
 constexpr int kBwdStages = kStagesL5 + 4 * kStagesHidden;               // 68
 constexpr int kBwdBlobFloats = kBwdStages * kStageFloats;
 constexpr int kBwdBlobOffset = kBlobFloats + kSmallFloats;              // 16-byte aligned
-constexpr int kPackedFloats = kBlobFloats + kSmallFloats + kBwdBlobFloats;
+// Split-precision ("f16x3") image of the inference path: the same 74 stages and the same bytes,
+// but every weight as an f16 pair (hi, lo) with hi + lo = 2^kWScaleLog2 * w to ~22 bits, for
+// v_mfma_f32_16x16x32_f16 (A: lane l holds A[row l & 15][k = 8 (l >> 4) + jj], jj = 0..7).
+// K is walked in blocks m of 32 features = two register tiles: MFMA k slot (kg = l >> 4, jj) is
+// feature 32 m + 16 (jj >> 2) + 4 kg + (jj & 3), i.e. lane group kg's registers of tiles 2m, 2m+1,
+// so the fp32 accumulator layout still chains layer to layer.  A stage is 8 (out tile, k block)
+// pairs x {hi slab, lo slab}; slab = 1 KiB [lane][8 halfs]; pair i at slabs 2i (hi), 2i+1 (lo).
+//   wide layers (KB = 3 for layer 0, 8 for layers 1..4): stage s of the layer = half * KB + m
+//                   (half = s / KB), pair i = out tile 8 * half + i of k block m
+//   layer 5:        stage s: pair i = (k block 2 s + (i >> 2), out tile i & 3)
+// Activations enter the MFMAs scaled by 2^kXScaleLog2 (folded into gamma/beta and the encoding),
+// so accumulators hold 2^12 * (W x + b); the "small" image of this path carries bias * 2^12,
+// gamma * 2^4, beta * 2^4 and LayerNorm runs with eps * 2^24 (all exact power-of-two scalings).
+constexpr int kWScaleLog2 = 8;
+constexpr int kXScaleLog2 = 4;
+constexpr int kHBlobOffset = kBwdBlobOffset + kBwdBlobFloats;
+constexpr int kHSmallOffset = kHBlobOffset + kBlobFloats;
+constexpr int kPackedFloats = kHSmallOffset + kSmallFloats;
 
 // flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts
 constexpr int kGradElements = kHidden * kEncIn + kHidden + 2 * kHidden

@@ -100,7 +100,7 @@ __device__ __forceinline__ void interleave_7() {
 template <bool kTrain>
 __device__ __forceinline__ LazyNorm finish_moments(const Moments& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
-                                                   float* save_rstd) {
+                                                   float* save_rstd, float eps = 1e-5f) {
     const float mean = group_sum(m.s) * (1.0f / 256.0f);
     const float ex2 = group_sum(m.q) * (1.0f / 256.0f);
     float var = ex2 - mean * mean;
@@ -116,7 +116,7 @@ __device__ __forceinline__ LazyNorm finish_moments(const Moments& m, const f32x4
         }
         var = group_sum(v) * (1.0f / 256.0f);
     }
-    const float ve = var + 1e-5f;
+    const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
     if (kTrain && g == 0) *save_rstd = rstd;
@@ -251,10 +251,196 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-precision ("f16x3") layers of the inference path: every fp32 operand is an f16 pair
+// (hi, lo) and a product is three v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi, fp32
+// accumulate; the dropped lo.lo term is ~2^-22 relative), 5.3x the fp32-MFMA rate per product.
+// Image and scalings: nerf_layout.h.  A k block m = register tiles 2m, 2m+1 of the input; its
+// B operands are built (normalise lazily like layer_fused, then split) one stage ahead.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 q2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ h2 pack_rtz(float a, float b) {
+    return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// (v0 | v1) -> hi, lo with hi + lo = v to ~22 bits.  Round-toward-zero never overflows to inf.
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, h8& hi, h8& lo) {
+    const h2 a = pack_rtz(v0.x, v0.y), b = pack_rtz(v0.z, v0.w), c = pack_rtz(v1.x, v1.y),
+             d = pack_rtz(v1.z, v1.w);
+    hi = h8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    const h2 la = pack_rtz(v0.x - (float)a.x, v0.y - (float)a.y),
+             lb = pack_rtz(v0.z - (float)b.x, v0.w - (float)b.y),
+             lc = pack_rtz(v1.x - (float)c.x, v1.y - (float)c.y),
+             ld = pack_rtz(v1.z - (float)d.x, v1.w - (float)d.y);
+    lo = h8{la.x, la.y, lb.x, lb.y, lc.x, lc.y, ld.x, ld.y};
+}
+
+// One group of the stage loop: two (out tile, k block) pairs = 6 MFMAs on the operands `a`
+// ([hi0, lo0, hi1, lo1]); the first MFMA is issued by the caller (it carries the operand wait).
+__device__ __forceinline__ void group_tail_h(const h8 (&a)[4], const h8& bh, const h8& bl, f32x4& y0,
+                                             f32x4& y1) {
+    y1 = mfma_h(a[2], bh, y1);
+    y0 = mfma_h(a[0], bl, y0);
+    y1 = mfma_h(a[2], bl, y1);
+    y0 = mfma_h(a[1], bh, y0);
+    y1 = mfma_h(a[3], bh, y1);
+}
+
+// "1 MFMA, then `valu` VALU instructions", 5 times (the tail of a group)
+template <int kValu>
+__device__ __forceinline__ void interleave_5() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);
+    }
+}
+
+// A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
+// the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
+// built during stage (0, m).
+template <int KB, bool kNormIn>
+__device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
+                                              const LazyNorm& norm, Moments& mom) {
+    h8 bhi[KB], blo[KB];
+    if (kNormIn) {
+        normalize_tile<false>(in[0], norm, 0);
+        normalize_tile<false>(in[1], norm, 1);
+    }
+    split8(in[0], in[1], bhi[0], blo[0]);
+    mom.s = mom.q = 0.f;
+    h8 a[2][4];
+    f32x4 ga0, be0, ga1, be1;
+    __builtin_amdgcn_s_setprio(0);
+    const h8* st = (const h8*)pipe.open_stage();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[0][k] = st[k * 64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int m = 0; m < KB; ++m) {
+            const bool last_stage = half == 1 && m == KB - 1;
+            const bool build_next = half == 0 && m + 1 < KB;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int cur = gq & 1, nxt = cur ^ 1;
+                const int T0 = 8 * half + 2 * gq, T1 = T0 + 1;
+                out[T0] = mfma_h(a[cur][0], bhi[m], out[T0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq < 3) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[nxt][k] = st[(4 * (gq + 1) + k) * 64];
+                    if (kNormIn && build_next && gq == 0) {
+                        ga0 = norm.gam[2 * m + 2];
+                        be0 = norm.bet[2 * m + 2];
+                        ga1 = norm.gam[2 * m + 3];
+                        be1 = norm.bet[2 * m + 3];
+                    }
+                } else if (!last_stage) {
+                    st = (const h8*)pipe.open_stage();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[nxt][k] = st[k * 64];
+                    pipe.prefetch_next();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                group_tail_h(a[cur], bhi[m], blo[m], out[T0], out[T1]);
+                // VALU riding in the shadow of this group's MFMAs
+                if (build_next && gq == 1 && kNormIn) {
+                    normalize_tile<false>(in[2 * m + 2], norm, 2 * m + 2, ga0, be0);
+                    normalize_tile<false>(in[2 * m + 3], norm, 2 * m + 3, ga1, be1);
+                    interleave_5<5>();
+                }
+                if (build_next && gq == 2) {
+                    split8(in[2 * m + 2], in[2 * m + 3], bhi[m + 1], blo[m + 1]);
+                    interleave_5<5>();
+                }
+                if (half == 1) {
+                    if (gq == 0) {                       // tiles 0..7, spread over the KB stages
+#pragma unroll
+                        for (int T = 0; T < 8; ++T)
+                            if (T * KB / 8 == m) mom.add(out[T]);
+                    } else if (last_stage) {             // pair finished one group ago
+                        mom.add(out[T0 - 2]);
+                        mom.add(out[T0 - 1]);
+                        interleave_5<4>();
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    mom.add(out[14]);
+    mom.add(out[15]);
+    __builtin_amdgcn_s_setprio(2);
+}
+
+// Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles.
+__device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
+                                            const LazyNorm& norm) {
+    h8 bh[2], bl[2];
+    normalize_tile<false>(in[0], norm, 0);
+    normalize_tile<false>(in[1], norm, 1);
+    split8(in[0], in[1], bh[0], bl[0]);
+    h8 a[2][4];
+    f32x4 ga0 = norm.gam[2], be0 = norm.bet[2], ga1 = norm.gam[3], be1 = norm.bet[3];
+    __builtin_amdgcn_s_setprio(0);
+    const h8* st = (const h8*)pipe.open_stage();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[0][k] = st[k * 64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int s = 0; s < kStagesL5; ++s) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int cur = gq & 1, nxt = cur ^ 1;
+            const int m = 2 * s + (gq >> 1);
+            const int T0 = 2 * (gq & 1), T1 = T0 + 1;
+            const int pb = m & 1;                        // B operand buffer of block m
+            acc[T0] = mfma_h(a[cur][0], bh[pb], acc[T0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (gq < 3) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[nxt][k] = st[(4 * (gq + 1) + k) * 64];
+            } else if (s + 1 < kStagesL5) {
+                st = (const h8*)pipe.open_stage();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[nxt][k] = st[k * 64];
+                pipe.prefetch_next();
+            }
+            if ((gq & 1) == 1 && m + 2 < 8) {            // a group ahead of the normalisation
+                ga0 = norm.gam[2 * m + 4];
+                be0 = norm.bet[2 * m + 4];
+                ga1 = norm.gam[2 * m + 5];
+                be1 = norm.bet[2 * m + 5];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            group_tail_h(a[cur], bh[pb], bl[pb], acc[T0], acc[T1]);
+            if (m + 1 < 8) {
+                if ((gq & 1) == 0) {
+                    normalize_tile<false>(in[2 * m + 2], norm, 2 * m + 2, ga0, be0);
+                    normalize_tile<false>(in[2 * m + 3], norm, 2 * m + 3, ga1, be1);
+                } else {
+                    split8(in[2 * m + 2], in[2 * m + 3], bh[pb ^ 1], bl[pb ^ 1]);
+                }
+                interleave_5<5>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(2);
+}
+
+// ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool kTrain>
+template <bool kTrain, bool kHalf>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
+    static_assert(!(kTrain && kHalf), "the split-precision path is inference only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -265,14 +451,14 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
     // small image -> LDS (once per workgroup)
     {
-        const float* small_g = a.packed + kBlobFloats;
+        const float* small_g = a.packed + (kHalf ? kHSmallOffset : kBlobFloats);
         float* small_l = (float*)smem;
         for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
     }
     const float* small = (const float*)smem;
 
     FwdPipe pipe;
-    pipe.init(a.packed, smem + kSmallLdsBytes, wave, lane);
+    pipe.init(a.packed + (kHalf ? kHBlobOffset : 0), smem + kSmallLdsBytes, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
@@ -334,9 +520,39 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;     // + ka.save.xhat[L]
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
-            // ---- layer 0: 96 -> 256 ----
             Moments mom;
             LazyNorm norm;
+            f32x4 out[4];
+            if (kHalf) {
+                // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
+                const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
+                                  (float)(1 << (kWScaleLog2 + kXScaleLog2));
+#pragma unroll
+                for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
+                load_bias16(small, g, Y);
+                layer_fused_h<3, false>(pipe, X, Y, norm, mom);
+                norm = finish_moments<false>(mom, Y, small, g, nullptr, nullptr, eps);
+#pragma unroll 1
+                for (int L = 1; L <= 3; L += 2) {
+                    const float* small_a = small + L * kSmallPerLayer;
+                    load_bias16(small_a, g, X);
+                    layer_fused_h<8, true>(pipe, Y, X, norm, mom);
+                    norm = finish_moments<false>(mom, X, small_a, g, nullptr, nullptr, eps);
+                    const float* small_b = small_a + kSmallPerLayer;
+                    load_bias16(small_b, g, Y);
+                    layer_fused_h<8, true>(pipe, X, Y, norm, mom);
+                    norm = finish_moments<false>(mom, Y, small_b, g, nullptr, nullptr, eps);
+                }
+                {
+                    const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) out[T] = b[T];
+                }
+                layer_out_h(pipe, Y, out, norm);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2)));
+            } else {
+            // ---- layer 0: 96 -> 256 ----
             load_bias16(small, g, Y);
             layer_fused<kStagesL0, false, kTrain>(pipe, X, Y, norm, mom);
             norm = finish_moments<kTrain>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0]);
@@ -350,13 +566,13 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                                               rstd_p + ka.save.rstd[L]);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----
-            f32x4 out[4];
             {
                 const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = b[T];
             }
             layer_out<kTrain>(pipe, X, out, norm);
+            }
             if (kTrain) {
                 float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
 #pragma unroll
@@ -458,6 +674,61 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int out = 16 * T + row;
             if (out < kOut) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
         }
+    } else if (e >= kHSmallOffset) {
+        // small image of the split-precision path: bias * 2^12, gamma * 2^4, beta * 2^4
+        const int i = e - kHSmallOffset;
+        const float sb = (float)(1 << (kWScaleLog2 + kXScaleLog2)), sx = (float)(1 << kXScaleLog2);
+        if (i < 5 * kSmallPerLayer) {
+            const int L = i / kSmallPerLayer, rem = i % kSmallPerLayer;
+            const int which = rem / kHidden, q = rem % kHidden;
+            const int g = q / 64, T = (q % 64) / 4, reg = q & 3;
+            const int f = 16 * T + 4 * g + reg;
+            const int tensor = which == 0 ? 4 * L + 1 : (which == 1 ? 4 * L + 2 : 4 * L + 3);
+            v = pa.p[tensor][f] * (which == 0 ? sb : sx);
+        } else {
+            const int q = i - 5 * kSmallPerLayer;
+            const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
+            const int n = 16 * T + 4 * g + reg;
+            if (n < kOut) v = pa.p[21][n] * sb;
+        }
+    } else if (e >= kHBlobOffset) {
+        // split-precision image (nerf_layout.h): this float slot carries two f16 of one slab
+        const int eb = e - kHBlobOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k;
+            const int tl = jj >> 2, r = jj & 3;           // tile 2 m + tl of the k block, register r
+            float w = 0.f;
+            if (stage < kStagesL0) {
+                const int half = stage / 3, m = stage % 3;
+                const int out = 16 * (8 * half + pair) + row;
+                w = pa.p[0][out * kEncIn + layer0_source_feature(2 * m + tl, kg, r)];
+            } else if (stage < kStagesL0 + 4 * kStagesHidden) {
+                const int L = 1 + (stage - kStagesL0) / kStagesHidden;
+                const int s = (stage - kStagesL0) % kStagesHidden;
+                const int half = s / 8, m = s % 8;
+                const int out = 16 * (8 * half + pair) + row;
+                w = pa.p[4 * L][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
+            } else {
+                const int s = stage - (kStagesL0 + 4 * kStagesHidden);
+                const int m = 2 * s + (pair >> 2), T = pair & 3;
+                const int out = 16 * T + row;
+                if (out < kOut) w = pa.p[20][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
+            }
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;              // round to nearest
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
     } else if (e >= kBwdBlobOffset) {
         // transposed image (nerf_layout.h): [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i]
         const int eb = e - kBwdBlobOffset;
@@ -550,6 +821,10 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     ka.save = make_train_layout(a.n_rays, ka.chunks);
     const bool train = a.train_workspace != nullptr;
+    if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
+    if (train && a.precision != NERF_HIP_PRECISION_FP32)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: the training forward is fp32 only");
     if (train && (a.out_raw != nullptr || a.out_mean != nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean are not produced by the training forward");
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave
@@ -561,23 +836,28 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static unsigned done_infer = 0, done_train = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false>, kLdsBytes, device,
+    static unsigned done_infer = 0, done_train = 0, done_half = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, false>, kLdsBytes, device,
                                          &done_infer);
     if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true>, kLdsBytes, device,
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true, false>, kLdsBytes, device,
                                          &done_train);
+    if (rc) return rc;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, true>, kLdsBytes, device,
+                                         &done_half);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64 KiB LDS, <= 256 VGPRs)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
     if (train) {
-        hipLaunchKernelGGL(nerf_render_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+        hipLaunchKernelGGL((nerf_render_fwd_kernel<true, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
-    } else
-        hipLaunchKernelGGL(nerf_render_fwd_kernel<false>, dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+    } else if (a.precision == NERF_HIP_PRECISION_F16X3)
+        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, true>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+    else
+        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

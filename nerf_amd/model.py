@@ -121,6 +121,9 @@ class NeRF(nn.Module):
         # rng: "torch" draws u / noise with torch's generator exactly where the reference does
         # (model.py:432, :652); "philox" lets the kernel draw them (no HBM round trip).
         self.rng = "torch"
+        # precision of the MLP in inference launches (anything that does not record a backward):
+        # "fp32" = exact-fp32 MFMA, "f16x3" = split-precision f16 MFMA (include/nerf_hip.h).
+        self.precision = "fp32"
         self._packed = None
         self._packed_key = None
         self._tables = {}
@@ -261,6 +264,9 @@ class NeRF(nn.Module):
         args.rgb, args.seg = _lib.ptr(rgb), _lib.ptr(seg)
         args.out_mean, args.out_raw, args.out_weights = _lib.ptr(mean), _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        args.precision = 0 if train_workspace is not None else _lib.PRECISIONS[self.precision]
 
     def _scratch(self, nbytes, device):
         """Cached scratch buffer for the backward's partial slabs."""

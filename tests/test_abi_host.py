@@ -32,9 +32,9 @@ def test_library_exports_every_declared_symbol(handle):
     for name in names:
         assert hasattr(handle, name), name
     assert set(_lib.EXPORTS) == set(names)
-    assert handle.nerf_hip_version() == 1
+    assert handle.nerf_hip_version() == 2
     # packed image = 74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB
-    assert handle.nerf_hip_packed_bytes() == 74 * 16384 + 3904 * 4 + 68 * 16384
+    assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4) + 68 * 16384
     assert handle.nerf_hip_grad_elements() == 304438
     assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 2793 * 4
     assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
