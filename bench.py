@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "fp32"))
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +151,7 @@ def main():
     from nerf_amd import NeRF, _lib
     torch.manual_seed(0)
     model = NeRF(focal_length=FOCAL).to(dev)         # default init, seed 0, on every rank
+    model.precision = args.precision
 
     # a batch of `world` poses on a circle of the same radius; rank r renders frame r (weak) or
     # its row block of frame 0 (strong)

@@ -86,14 +86,28 @@ struct WeightPipe {
     __device__ __forceinline__ void issue() {
         {
             // one address + one M0 base, the four 1 KiB pieces by the instruction's immediate
-            // offset (it applies to the global and the LDS address alike)
-            const auto* src = (const __attribute__((address_space(1))) char*)(
-                blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16);
-            auto* dst = (__attribute__((address_space(3))) char*)(ring + issue_slot * kStageBytes + wave * 4096);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+            // offset (it applies to the global and the LDS address alike).
+            // Written as inline asm on purpose: once the compiler sees an LDS-DMA builtin in a
+            // function, its wait-count pass stops counting LDS reads and drains them all
+            // (s_waitcnt lgkmcnt(0)) before every use, which defeats issuing ds_reads ahead of
+            // the MFMAs that consume them.  The DMA's own completion is tracked by hand anyway
+            // (open_stage: vmcnt(4) + barrier); DMA ops the compiler does not know about only make
+            // its own vmcnt waits more conservative, never too weak (vector memory returns in order).
+            const char* src = blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16;
+            const uint32_t dst = (uint32_t)(uintptr_t)(ring + issue_slot * kStageBytes + wave * 4096);
+            uint32_t m0_saved;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(m0_saved)
+                : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                : "memory");
         }
         issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;
         issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;

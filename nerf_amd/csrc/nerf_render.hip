@@ -46,8 +46,13 @@ struct LazyNorm {
     float* save_row;            // training: this lane's x_hat row (tile T at + 16 T), else unused
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct Moments {
     float s, q;
+    __device__ __forceinline__ void reset() { s = q = 0.f; }
+    __device__ __forceinline__ float sum() const { return s; }
+    __device__ __forceinline__ float sum_sq() const { return q; }
     __device__ __forceinline__ void add(const f32x4& v) {
 #ifdef NERF_ABL_LN
         return;
@@ -60,7 +65,28 @@ struct Moments {
     }
 };
 
-template <bool kTrain>
+// Same with two partial sums each, so that the adds and fmas go out as packed fp32 instructions
+// (v_pk_add_f32 / v_pk_fma_f32: two values per issue slot); used where VALU issue is the limit
+// (the split-precision path).  Packed operands need aligned register pairs, which costs the
+// fp32 kernels more registers than it saves them issue slots.
+struct MomentsPk {
+    f32x2 s, q;
+    __device__ __forceinline__ void reset() { s = q = f32x2{0.f, 0.f}; }
+    __device__ __forceinline__ float sum() const { return s.x + s.y; }
+    __device__ __forceinline__ float sum_sq() const { return q.x + q.y; }
+    __device__ __forceinline__ void add(const f32x4& v) {
+#ifdef NERF_ABL_LN
+        return;
+#endif
+        const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+        s += a;
+        q = a * a + q;
+        s += b;
+        q = b * b + q;
+    }
+};
+
+template <bool kTrain, bool kPacked = false>
 __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T, const f32x4& ga,
                                                const f32x4& be) {
     f32x4 xh;
@@ -69,16 +95,21 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
     for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaxf(x[r], 0.f);
     return;
 #endif
+    if (kPacked) {
+        xh = x * n.rstd + n.shift;              // packed fp32 fmas, two values per instruction
+        x = __builtin_elementwise_max(xh * ga + be, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        xh[r] = __builtin_fmaf(x[r], n.rstd, n.shift);
-        x[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
+        for (int r = 0; r < 4; ++r) {
+            xh[r] = __builtin_fmaf(x[r], n.rstd, n.shift);
+            x[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
+        }
     }
     if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
 }
-template <bool kTrain>
+template <bool kTrain, bool kPacked = false>
 __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T) {
-    normalize_tile<kTrain>(x, n, T, n.gam[T], n.bet[T]);
+    normalize_tile<kTrain, kPacked>(x, n, T, n.gam[T], n.bet[T]);
 }
 
 // "1 MFMA, then `valu` VALU instructions", 7 times: spreads a region's VALU work over the gaps of
@@ -97,12 +128,12 @@ __device__ __forceinline__ void interleave_7() {
 // the second moment in ANY sample of the wave, the exact two-pass variance is taken instead
 // (wave-uniform branch; pre-LayerNorm activations of this network have |mean| well below std, so
 // it is cold).  1/sqrt: hardware estimate (1 ulp) + one Newton step.
-template <bool kTrain>
-__device__ __forceinline__ LazyNorm finish_moments(const Moments& m, const f32x4 (&raw)[16],
+template <bool kTrain, class Mom>
+__device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
                                                    float* save_rstd, float eps = 1e-5f) {
-    const float mean = group_sum(m.s) * (1.0f / 256.0f);
-    const float ex2 = group_sum(m.q) * (1.0f / 256.0f);
+    const float mean = group_sum(m.sum()) * (1.0f / 256.0f);
+    const float ex2 = group_sum(m.sum_sq()) * (1.0f / 256.0f);
     float var = ex2 - mean * mean;
     if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
         float v = 0.f;
@@ -144,7 +175,7 @@ template <int KT, bool kNormIn, bool kTrain>
 __device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
                                             const LazyNorm& norm, Moments& mom) {
     if (kNormIn) normalize_tile<kTrain>(in[0], norm, 0);
-    mom.s = mom.q = 0.f;
+    mom.reset();
     f32x4 a[2][2];
     f32x4 ga, be;               // gamma / beta of the tile being normalised next
     __builtin_amdgcn_s_setprio(0);
@@ -257,6 +288,23 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
 // Image and scalings: nerf_layout.h.  A k block m = register tiles 2m, 2m+1 of the input; its
 // B operands are built (normalise lazily like layer_fused, then split) one stage ahead.
 // ---------------------------------------------------------------------------------------------
+#ifdef NERF_EXP_NOLDS         /* timing experiment only: operands are not re-read */
+#define LDSRD(x, keep) (keep)
+#else
+#define LDSRD(x, keep) (x)
+#endif
+// packed fp32 in the normalisation costs aligned register pairs: at this register pressure it
+// spills inside the layer loops (150 ms per frame against 136), so only the moments are packed
+#ifdef NERF_EXP_PACKNORM
+constexpr bool kPackNorm = true;
+#else
+constexpr bool kPackNorm = false;
+#endif
+#ifdef NERF_EXP_NOPACKMOM
+typedef Moments HMoments;
+#else
+typedef MomentsPk HMoments;
+#endif
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __fp16 q2 __attribute__((ext_vector_type(2)));
@@ -267,167 +315,203 @@ __device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c
 __device__ __forceinline__ h2 pack_rtz(float a, float b) {
     return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
 }
+// x - (float)pair[kHigh] in one instruction (v_fma_mix_f32 reads the f16 half directly)
+template <int kHigh>
+__device__ __forceinline__ float residual(float x, const h2& pair) {
+    float r;
+    if (kHigh)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+    return r;
+}
+
+// (v | .) half of split8: one register tile -> its four hi and four lo halfs
+__device__ __forceinline__ void split4(const f32x4& v, h2& hi0, h2& hi1, h2& lo0, h2& lo1) {
+    hi0 = pack_rtz(v.x, v.y);
+    hi1 = pack_rtz(v.z, v.w);
+#ifdef NERF_ABL_SPLIT        /* timing experiment only */
+    lo0 = hi0;
+    lo1 = hi1;
+    return;
+#endif
+    lo0 = pack_rtz(residual<0>(v.x, hi0), residual<1>(v.y, hi0));
+    lo1 = pack_rtz(residual<0>(v.z, hi1), residual<1>(v.w, hi1));
+}
+__device__ __forceinline__ h8 join8(const h2& a, const h2& b, const h2& c, const h2& d) {
+    return h8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+
 // (v0 | v1) -> hi, lo with hi + lo = v to ~22 bits.  Round-toward-zero never overflows to inf.
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, h8& hi, h8& lo) {
-    const h2 a = pack_rtz(v0.x, v0.y), b = pack_rtz(v0.z, v0.w), c = pack_rtz(v1.x, v1.y),
-             d = pack_rtz(v1.z, v1.w);
-    hi = h8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-    const h2 la = pack_rtz(v0.x - (float)a.x, v0.y - (float)a.y),
-             lb = pack_rtz(v0.z - (float)b.x, v0.w - (float)b.y),
-             lc = pack_rtz(v1.x - (float)c.x, v1.y - (float)c.y),
-             ld = pack_rtz(v1.z - (float)d.x, v1.w - (float)d.y);
-    lo = h8{la.x, la.y, lb.x, lb.y, lc.x, lc.y, ld.x, ld.y};
+    h2 nh[4], nl[4];
+    split4(v0, nh[0], nh[1], nl[0], nl[1]);
+    split4(v1, nh[2], nh[3], nl[2], nl[3]);
+    hi = join8(nh[0], nh[1], nh[2], nh[3]);
+    lo = join8(nl[0], nl[1], nl[2], nl[3]);
 }
 
-// One group of the stage loop: two (out tile, k block) pairs = 6 MFMAs on the operands `a`
-// ([hi0, lo0, hi1, lo1]); the first MFMA is issued by the caller (it carries the operand wait).
-__device__ __forceinline__ void group_tail_h(const h8 (&a)[4], const h8& bh, const h8& bl, f32x4& y0,
-                                             f32x4& y1) {
-    y1 = mfma_h(a[2], bh, y1);
-    y0 = mfma_h(a[0], bl, y0);
-    y1 = mfma_h(a[2], bl, y1);
-    y0 = mfma_h(a[1], bh, y0);
-    y1 = mfma_h(a[3], bh, y1);
-}
-
-// "1 MFMA, then `valu` VALU instructions", 5 times (the tail of a group)
+// "1 MFMA, then `valu` VALU instructions", twice (the tail of a unit)
 template <int kValu>
-__device__ __forceinline__ void interleave_5() {
+__device__ __forceinline__ void interleave_2() {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);
     }
 }
 
+// A-operand register sets of the unit pipeline: a unit = one (out tile, k block) pair = two
+// ds_read_b128 (hi slab, lo slab) and three MFMAs (48 cycles); the reads of unit U + kSets - 1 are
+// issued right after the first MFMA of unit U, so an LDS read has kSets - 1 units to land (the
+// compiler's counted lgkmcnt waits leave the younger reads in flight).  A stage's hand-over
+// (vmcnt wait, barrier, DMA issue) therefore sits kSets - 1 units before the stage's first MFMA;
+// at that barrier every wave has issued AND retired (lgkmcnt(0)) all reads of the stage it is
+// still computing on, whose slot the DMA issued next overwrites.
+constexpr int kSets = 4;
+
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
-// built during stage (0, m).
+// built (normalise tile by tile, then split) during stage (0, m).
 template <int KB, bool kNormIn>
 __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
-                                              const LazyNorm& norm, Moments& mom) {
+                                              const LazyNorm& norm, HMoments& mom) {
+    constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
     h8 bhi[KB], blo[KB];
     if (kNormIn) {
-        normalize_tile<false>(in[0], norm, 0);
-        normalize_tile<false>(in[1], norm, 1);
+        normalize_tile<false, kPackNorm>(in[0], norm, 0);
+        normalize_tile<false, kPackNorm>(in[1], norm, 1);
     }
     split8(in[0], in[1], bhi[0], blo[0]);
-    mom.s = mom.q = 0.f;
-    h8 a[2][4];
-    f32x4 ga0, be0, ga1, be1;
+    mom.reset();
+    h8 ah[kSets], al[kSets];
+    f32x4 ga, be;
+    h2 nh[4], nl[4];                                     // halves of the block being built
     __builtin_amdgcn_s_setprio(0);
     const h8* st = (const h8*)pipe.open_stage();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[0][k] = st[k * 64];
+    for (int u = 0; u < kSets - 1; ++u) {
+        ah[u] = st[(2 * u) * 64];
+        al[u] = st[(2 * u + 1) * 64];
+    }
     pipe.prefetch_next();
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int s = 0; s < kStages; ++s) {
+        const int half = s / KB, m = s % KB;
+        const bool build_next = half == 0 && m + 1 < KB;
+        const int ta = 2 * m + 2, tb = 2 * m + 3;        // tiles of block m + 1
 #pragma unroll
-        for (int m = 0; m < KB; ++m) {
-            const bool last_stage = half == 1 && m == KB - 1;
-            const bool build_next = half == 0 && m + 1 < KB;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int cur = gq & 1, nxt = cur ^ 1;
-                const int T0 = 8 * half + 2 * gq, T1 = T0 + 1;
-                out[T0] = mfma_h(a[cur][0], bhi[m], out[T0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (gq < 3) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[nxt][k] = st[(4 * (gq + 1) + k) * 64];
-                    if (kNormIn && build_next && gq == 0) {
-                        ga0 = norm.gam[2 * m + 2];
-                        be0 = norm.bet[2 * m + 2];
-                        ga1 = norm.gam[2 * m + 3];
-                        be1 = norm.bet[2 * m + 3];
-                    }
-                } else if (!last_stage) {
-                    st = (const h8*)pipe.open_stage();
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[nxt][k] = st[k * 64];
-                    pipe.prefetch_next();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                group_tail_h(a[cur], bhi[m], blo[m], out[T0], out[T1]);
-                // VALU riding in the shadow of this group's MFMAs
-                if (build_next && gq == 1 && kNormIn) {
-                    normalize_tile<false>(in[2 * m + 2], norm, 2 * m + 2, ga0, be0);
-                    normalize_tile<false>(in[2 * m + 3], norm, 2 * m + 3, ga1, be1);
-                    interleave_5<5>();
-                }
-                if (build_next && gq == 2) {
-                    split8(in[2 * m + 2], in[2 * m + 3], bhi[m + 1], blo[m + 1]);
-                    interleave_5<5>();
-                }
-                if (half == 1) {
-                    if (gq == 0) {                       // tiles 0..7, spread over the KB stages
-#pragma unroll
-                        for (int T = 0; T < 8; ++T)
-                            if (T * KB / 8 == m) mom.add(out[T]);
-                    } else if (last_stage) {             // pair finished one group ago
-                        mom.add(out[T0 - 2]);
-                        mom.add(out[T0 - 1]);
-                        interleave_5<4>();
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 8; ++i) {
+            const int U = 8 * s + i, set = U % kSets;
+            const int T = 8 * half + i;
+            out[T] = mfma_h(ah[set], bhi[m], out[T]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (U + kSets - 1 < kUnits) {
+                const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
+                if (ip == 0) st = (const h8*)pipe.open_stage();
+                ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
+                al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
+                if (ip == 0) pipe.prefetch_next();
             }
+            if (kNormIn && build_next && (i == 0 || i == 2)) {   // a unit ahead of their use
+                ga = norm.gam[i == 0 ? ta : tb];
+                be = norm.bet[i == 0 ? ta : tb];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            out[T] = mfma_h(ah[set], blo[m], out[T]);
+            out[T] = mfma_h(al[set], bhi[m], out[T]);
+            // VALU riding in the shadow of this unit's MFMAs
+            if (build_next) {
+                if (kNormIn && i == 1) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (i == 2) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
+                if (kNormIn && i == 3) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (i == 4) {
+                    split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
+                    bhi[m + 1] = join8(nh[0], nh[1], nh[2], nh[3]);
+                    blo[m + 1] = join8(nl[0], nl[1], nl[2], nl[3]);
+                }
+                if (i >= 1 && i <= 4) interleave_2<4>();
+            }
+            if (half == 1) {
+                // tiles 0..7 (finished in the first half), spread over the second half's stages
+#pragma unroll
+                for (int T2 = 0; T2 < 8; ++T2) {
+                    const int first = (8 * m + KB - 1) / KB;             // first tile of stage m
+                    if (T2 * KB / 8 == m && i == (s + 1 < kStages ? T2 - first : 0)) {
+                        mom.add(out[T2]);
+                        if (s + 1 < kStages) interleave_2<2>();
+                    }
+                }
+                if (s + 1 == kStages && i >= 1) {        // tile finished one unit ago
+                    mom.add(out[T - 1]);
+                    interleave_2<2>();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    mom.add(out[14]);
     mom.add(out[15]);
     __builtin_amdgcn_s_setprio(2);
 }
 
-// Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles.
+// Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
+// block m + 1 is built during the four units of block m.
 __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
                                             const LazyNorm& norm) {
+    constexpr int kUnits = 8 * kStagesL5;
     h8 bh[2], bl[2];
-    normalize_tile<false>(in[0], norm, 0);
-    normalize_tile<false>(in[1], norm, 1);
+    normalize_tile<false, kPackNorm>(in[0], norm, 0);
+    normalize_tile<false, kPackNorm>(in[1], norm, 1);
     split8(in[0], in[1], bh[0], bl[0]);
-    h8 a[2][4];
-    f32x4 ga0 = norm.gam[2], be0 = norm.bet[2], ga1 = norm.gam[3], be1 = norm.bet[3];
+    h8 ah[kSets], al[kSets];
+    f32x4 ga = norm.gam[2], be = norm.bet[2];
+    h2 nh[4], nl[4];
     __builtin_amdgcn_s_setprio(0);
     const h8* st = (const h8*)pipe.open_stage();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[0][k] = st[k * 64];
+    for (int u = 0; u < kSets - 1; ++u) {
+        ah[u] = st[(2 * u) * 64];
+        al[u] = st[(2 * u + 1) * 64];
+    }
     pipe.prefetch_next();
 #pragma unroll
     for (int s = 0; s < kStagesL5; ++s) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int cur = gq & 1, nxt = cur ^ 1;
-            const int m = 2 * s + (gq >> 1);
-            const int T0 = 2 * (gq & 1), T1 = T0 + 1;
-            const int pb = m & 1;                        // B operand buffer of block m
-            acc[T0] = mfma_h(a[cur][0], bh[pb], acc[T0]);
+        for (int i = 0; i < 8; ++i) {
+            const int U = 8 * s + i, set = U % kSets;
+            const int m = 2 * s + (i >> 2), T = i & 3, q = i & 3;
+            const int pb = m & 1;
+            const int ta = 2 * m + 2, tb = 2 * m + 3;
+            acc[T] = mfma_h(ah[set], bh[pb], acc[T]);
             __builtin_amdgcn_sched_barrier(0);
-            if (gq < 3) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[nxt][k] = st[(4 * (gq + 1) + k) * 64];
-            } else if (s + 1 < kStagesL5) {
-                st = (const h8*)pipe.open_stage();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[nxt][k] = st[k * 64];
-                pipe.prefetch_next();
+            if (U + kSets - 1 < kUnits) {
+                const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
+                if (ip == 0) st = (const h8*)pipe.open_stage();
+                ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
+                al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
+                if (ip == 0) pipe.prefetch_next();
             }
-            if ((gq & 1) == 1 && m + 2 < 8) {            // a group ahead of the normalisation
-                ga0 = norm.gam[2 * m + 4];
-                be0 = norm.bet[2 * m + 4];
-                ga1 = norm.gam[2 * m + 5];
-                be1 = norm.bet[2 * m + 5];
+            if (q == 1 && m + 1 < 8) {
+                ga = norm.gam[tb];
+                be = norm.bet[tb];
+            }
+            if (q == 3 && m + 2 < 8) {
+                ga = norm.gam[ta + 2];
+                be = norm.bet[ta + 2];
             }
             __builtin_amdgcn_sched_barrier(0);
-            group_tail_h(a[cur], bh[pb], bl[pb], acc[T0], acc[T1]);
+            acc[T] = mfma_h(ah[set], bl[pb], acc[T]);
+            acc[T] = mfma_h(al[set], bh[pb], acc[T]);
             if (m + 1 < 8) {
-                if ((gq & 1) == 0) {
-                    normalize_tile<false>(in[2 * m + 2], norm, 2 * m + 2, ga0, be0);
-                    normalize_tile<false>(in[2 * m + 3], norm, 2 * m + 3, ga1, be1);
-                } else {
-                    split8(in[2 * m + 2], in[2 * m + 3], bh[pb ^ 1], bl[pb ^ 1]);
+                if (q == 0) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (q == 1) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
+                if (q == 2) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (q == 3) {
+                    split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
+                    bh[pb ^ 1] = join8(nh[0], nh[1], nh[2], nh[3]);
+                    bl[pb ^ 1] = join8(nl[0], nl[1], nl[2], nl[3]);
                 }
-                interleave_5<5>();
+                interleave_2<4>();
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -520,10 +604,10 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;     // + ka.save.xhat[L]
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
-            Moments mom;
             LazyNorm norm;
             f32x4 out[4];
             if (kHalf) {
+                HMoments mom;
                 // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
                 const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
                                   (float)(1 << (kWScaleLog2 + kXScaleLog2));
@@ -531,17 +615,17 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
                 load_bias16(small, g, Y);
                 layer_fused_h<3, false>(pipe, X, Y, norm, mom);
-                norm = finish_moments<false>(mom, Y, small, g, nullptr, nullptr, eps);
+                norm = finish_moments<false, HMoments>(mom, Y, small, g, nullptr, nullptr, eps);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
                     const float* small_a = small + L * kSmallPerLayer;
                     load_bias16(small_a, g, X);
                     layer_fused_h<8, true>(pipe, Y, X, norm, mom);
-                    norm = finish_moments<false>(mom, X, small_a, g, nullptr, nullptr, eps);
+                    norm = finish_moments<false, HMoments>(mom, X, small_a, g, nullptr, nullptr, eps);
                     const float* small_b = small_a + kSmallPerLayer;
                     load_bias16(small_b, g, Y);
                     layer_fused_h<8, true>(pipe, X, Y, norm, mom);
-                    norm = finish_moments<false>(mom, Y, small_b, g, nullptr, nullptr, eps);
+                    norm = finish_moments<false, HMoments>(mom, Y, small_b, g, nullptr, nullptr, eps);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
@@ -552,17 +636,18 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2)));
             } else {
+            Moments mom;
             // ---- layer 0: 96 -> 256 ----
             load_bias16(small, g, Y);
             layer_fused<kStagesL0, false, kTrain>(pipe, X, Y, norm, mom);
-            norm = finish_moments<kTrain>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0]);
+            norm = finish_moments<kTrain, Moments>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0]);
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
             for (int L = 1; L <= 4; ++L) {
                 const float* small_l = small + L * kSmallPerLayer;
                 load_bias16(small_l, g, Y);
                 layer_fused<kStagesHidden, true, kTrain>(pipe, X, Y, norm, mom);
-                norm = finish_moments<kTrain>(mom, X, small_l, g, xrow + ka.save.xhat[L],
+                norm = finish_moments<kTrain, Moments>(mom, X, small_l, g, xrow + ka.save.xhat[L],
                                               rstd_p + ka.save.rstd[L]);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----

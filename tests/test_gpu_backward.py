@@ -102,7 +102,7 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
                                  density_noise_std=0.5, u=u.to(dev), noise=noise.to(dev))
     loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + ((seg[:, 0] * w_seg.to(dev)).sum() if with_seg else 0.0)
     loss.backward()
-    assert abs(float(loss) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-4 * max(1.0, abs(float(loss_r.detach())))
     def loss64(p):
         a, b = O.render_rays(p, CFG, o.double(), d.double(), num_samples, u=u.double(),
                              noise=noise.double(), density_noise_std=0.5)

@@ -21,16 +21,30 @@ def dev():
     return torch.device("cuda:0")
 
 
+_PRECISION = "fp32"
+
+
+@pytest.fixture(params=["fp32", "f16x3"], autouse=True)
+def precision(request):
+    """Every test of this module runs on both MLP arithmetics of the inference kernel (exact-fp32
+    MFMA and the split-precision f16 path) against the SAME tolerances."""
+    global _PRECISION
+    _PRECISION = request.param
+    yield request.param
+    _PRECISION = "fp32"
+
+
 def make_model(dev, scale=1.0, focal_length=112.0, params=None):
     from nerf_amd import NeRF
     model = NeRF(focal_length=focal_length)
     model.load_state_dict(params if params is not None else golden_params(scale))
+    model.precision = _PRECISION
     return model.to(dev)
 
 
 def test_library_loaded_and_no_cpu_path(dev):
     from nerf_amd import _lib
-    assert _lib.lib().nerf_hip_version() == 1
+    assert _lib.lib().nerf_hip_version() == _lib.ABI_VERSION == 2
     model = make_model(dev)
     with pytest.raises(RuntimeError):
         model.render_rays(torch.zeros(4, 3), torch.ones(4, 3), 8)
@@ -221,6 +235,7 @@ def test_batched_poses_nondefault_box_and_focal(dev):
     params["rays_max"] = torch.tensor([[[6.0, 7.0, 8.0]]])
     model = NeRF(focal_length=50.0, min_x=-6.0, max_x=6.0, min_y=-5.0, max_y=7.0, min_z=-4.0, max_z=8.0)
     model.load_state_dict(params)
+    model.precision = _PRECISION
     model = model.to(dev)
     yaw, elev = torch.tensor([0.3, 1.9, -2.2]), torch.tensor([0.4, 0.2, 0.9])
     pos = NeRF.spherical_to_cartesian(yaw, elev) * 3.0
