@@ -11,9 +11,16 @@ deterministic fenceposts, RGB + 50-class segmentation composited): the whole hot
 N poses one frame each with no data-path collective ("weak" scaling; ``--scaling strong`` splits
 ONE frame into row blocks instead).  Rank 0 prints one JSON line.
 
-roofline: the render kernel is MFMA-bound (exact-fp32 v_mfma_f32_16x16x4_f32); achieved =
-evaluated samples per launch x 601,088 FLOP / average kernel duration measured with HIP events
-on the launch stream; peak = 157.3 TFLOP/s (fp32 matrix peak, MI355X_MICROARCH.md).
+Two arithmetics of the same kernel (NerfHipRenderArgs.precision), both held to
+the same parity tests: "f16x3" (default here: every fp32 product as three f16 MFMAs with fp32
+accumulation, v_mfma_f32_16x16x32_f16) and "fp32" (exact-fp32 v_mfma_f32_16x16x4_f32).  The
+headline `value` is the selected precision's; at N=1 the other one is measured in the same run and
+reported beside it (`other_precision`).
+
+roofline: the render kernel is MFMA-bound; achieved = evaluated samples per launch x 601,088
+ALGORITHMIC FLOP / average kernel duration measured with HIP events on the launch stream; peak =
+the dense MFMA peak of the instruction's input type (MI355X_MICROARCH.md): 157.3 TFLOP/s fp32,
+2516.6 TFLOP/s f16.  The f16x3 path executes 3 MFMA FLOP per algorithmic FLOP (`executed_frac`).
 cpu_baseline: the oracle (a torch-CPU port of the reference, oracle/nerf_oracle.py) timed on
 this box's host cores on a bounded block of rows of the same frame.
 """
@@ -34,6 +41,15 @@ SAMPLES = 128
 FOCAL = 896.0
 FLOP_PER_SAMPLE = 601088          # 2*(96*256 + 4*256*256 + 256*54), SURVEY.md section 8d
 PEAK_TFLOPS_FP32_MFMA = 157.3     # MI355X_MICROARCH.md, chip-level parameters
+PEAK_TFLOPS_F16_MFMA = 2516.6     # dense f16/bf16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+PRECISIONS = {
+    "fp32": {"dtype": "f32", "peak": PEAK_TFLOPS_FP32_MFMA, "mfma_per_product": 1,
+             "peak_note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peak; algorithmic FLOPs only"},
+    "f16x3": {"dtype": "f16x3 (f32 accumulate)", "peak": PEAK_TFLOPS_F16_MFMA, "mfma_per_product": 3,
+              "peak_note": "dense f16 MFMA (v_mfma_f32_16x16x32_f16) peak; `achieved`/`frac` count "
+                           "ALGORITHMIC FLOPs, the kernel executes 3 MFMA FLOP per algorithmic FLOP "
+                           "(hi.hi + hi.lo + lo.hi): executed_frac = 3 x frac"},
+}
 CAMERA = (0.0, -3.0, 2.6)
 
 
@@ -103,14 +119,16 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
             "tflops_fwd_dgrad_wgrad": tflops, "frac_of_fp32_mfma_peak": tflops / PEAK_TFLOPS_FP32_MFMA}
 
 
-def profiled_traffic():
+def profiled_traffic(precision):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/*_pmc_summary.json; FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per
-    the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the
-    timed process, so this is the last profiled value, or None."""
+    same command (profiles/*_pmc_summary.json, the newest one of this precision; FETCH_SIZE/WRITE_SIZE
+    are KiB, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside the timed process, so this is the last profiled value, or None."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        if ("f16x3" in os.path.basename(path)) != (precision == "f16x3"):
+            continue
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -120,6 +138,31 @@ def profiled_traffic():
     return best
 
 
+def roofline(precision, rays, kernel_ms, launches, with_traffic):
+    evaluated = rays * (SAMPLES - 1)
+    info = PRECISIONS[precision]
+    achieved = evaluated * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
+    traffic = profiled_traffic(precision) if with_traffic else None
+    return {
+        "bound": "mfma",
+        "achieved": achieved,
+        "peak": info["peak"],
+        "unit": "TFLOP/s",
+        "frac": achieved / info["peak"] if achieved else None,
+        "traffic": traffic[0] if traffic else None,
+        "traffic_unit": "bytes/launch",
+        "traffic_source": traffic[1] if traffic else None,
+        "algorithmic_bytes": rays * (12 + 200) + 48,
+        "kernel": "nerf_render_fwd_kernel",
+        "kernel_ms": kernel_ms,
+        "launches_timed": launches,
+        "flop_per_launch": evaluated * FLOP_PER_SAMPLE,
+        "executed_mfma_flop_per_launch": evaluated * FLOP_PER_SAMPLE * info["mfma_per_product"],
+        "executed_frac": achieved * info["mfma_per_product"] / info["peak"] if achieved else None,
+        "peak_note": info["peak_note"],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +170,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "fp32"))
+    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "f16x3"))
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,19 +221,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _lib.timing(True)
-    _lib.timing_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = _lib.timing_read(reset=True)
-    _lib.timing(False)
-    assert torch.isfinite(out[0]).all()
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            step()
+        fence()
+        _lib.timing(True)
+        _lib.timing_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = _lib.timing_read(reset=True)
+        _lib.timing(False)
+        assert torch.isfinite(out[0]).all()
+        return dt, kernel_ms, launches
+
+    elapsed, kernel_ms, launches = timed(args.steps, args.warmup)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
     if distributed:
@@ -202,9 +249,6 @@ def main():
     value = total_rays * SAMPLES * args.steps / elapsed
 
     if rank == 0:
-        evaluated = rays_per_rank * (SAMPLES - 1)
-        achieved = evaluated * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
-        traffic = profiled_traffic() if (world == 1 and args.scaling == "weak") else None
         line = {
             "metric": "ray-samples/sec at 800x800x128",
             "value": value,
@@ -216,34 +260,34 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": PRECISIONS[args.precision]["dtype"],
             "data": "synthetic",
             "config": {
                 "workload": "NeRF.render_image 800x800, 128 samples/ray (127 evaluated), RGB + 50-class "
                             "segmentation, rays generated in-kernel, default-init weights seed 0",
+                "precision": args.precision,
                 "rays_per_gpu": rays_per_rank,
                 "frames": world if args.scaling == "weak" else 1,
                 "sharding": "one frame per GPU" if args.scaling == "weak" else "row blocks of one frame",
                 "collectives": "none",
                 "rendezvous_backend": backend,
             },
-            "roofline": {
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_TFLOPS_FP32_MFMA,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS_FP32_MFMA if achieved else None,
-                "traffic": traffic[0] if traffic else None,
-                "traffic_unit": "bytes/launch",
-                "traffic_source": traffic[1] if traffic else None,
-                "algorithmic_bytes": rays_per_rank * (12 + 200) + 48,
-                "kernel": "nerf_render_fwd_kernel",
-                "kernel_ms": kernel_ms,
-                "launches_timed": launches,
-                "flop_per_launch": evaluated * FLOP_PER_SAMPLE,
-                "peak_note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peak; algorithmic FLOPs only",
-            },
+            "roofline": roofline(args.precision, rays_per_rank, kernel_ms, launches,
+                                 world == 1 and args.scaling == "weak"),
         }
+        if world == 1 and not args.no_cpu_baseline:
+            # the other arithmetic of the same kernel, same frame, same run
+            other = "fp32" if args.precision == "f16x3" else "f16x3"
+            model.precision = other
+            o_steps = max(3, args.steps // 4)
+            o_elapsed, o_kernel_ms, o_launches = timed(o_steps, 1)
+            model.precision = args.precision
+            line["other_precision"] = {
+                "precision": other, "dtype": PRECISIONS[other]["dtype"],
+                "value": rays_per_rank * SAMPLES * o_steps / o_elapsed, "unit": "ray-samples/s",
+                "steps": o_steps, "ms_per_step": o_elapsed / o_steps * 1e3,
+                "roofline": roofline(other, rays_per_rank, o_kernel_ms, o_launches, True),
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["train_step"] = train_step_timing(dev)
             line["cpu_baseline"] = cpu_baseline()

@@ -520,7 +520,14 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
 // one coalesced store instruction per output row
 __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t local, bool ray_ok, int lane,
                                           const RayAccum& acc) {
-    if (ray_ok && lane < 3) a.rgb[local * 3 + lane] = lane == 0 ? acc.rgb0 : (lane == 1 ? acc.rgb1 : acc.rgb2);
+    // lane 0 stores the three sums (a per-lane select of acc.rgb0/1/2 by lane id makes the compiler
+    // index the accumulator struct dynamically, which pins it to a scratch-memory stack object that
+    // is then re-written every chunk)
+    if (ray_ok && lane == 0) {
+        a.rgb[local * 3 + 0] = acc.rgb0;
+        a.rgb[local * 3 + 1] = acc.rgb1;
+        a.rgb[local * 3 + 2] = acc.rgb2;
+    }
     if (a.seg != nullptr) {
         // the wave's 64 lanes cover n = 0..63 once: the 50 class values leave in one store
         const int j = lane & 15, g = lane >> 4;

@@ -16,6 +16,13 @@ using namespace nerf_device;
 namespace {
 
 constexpr int kLdsBytes = kSmallLdsBytes + kRing * kStageBytes;   // 64 KiB -> 2 workgroups / CU
+// Split-precision kernel: per-lane state that only the front end and the compositing need (ray,
+// running transmittance / RGB / segmentation sums, interval length) is parked in LDS while the MLP
+// runs, instead of being spilled to scratch (= HBM writes) by the register allocator.
+constexpr int kStashFloatsPerLane = 8;
+constexpr int kStashBytes = kWavesPerWg * 64 * kStashFloatsPerLane * 4;   // 8 KiB
+constexpr int kRayStashBytes = kWavesPerWg * 8 * 4;
+constexpr int kLdsBytesHalf = kLdsBytes + kStashBytes + kRayStashBytes;   // 72.1 KiB -> still 2 / CU
 
 struct KernelArgs {
     NerfHipRenderArgs a;
@@ -569,9 +576,16 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
         int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
-        const Ray ray = load_ray(a, local);
+        Ray ray = load_ray(a, local);
         RayAccum racc;
         racc.reset();
+        float* const stash = (float*)(smem + kLdsBytes) + (wave * 64 + lane) * kStashFloatsPerLane;
+        float* const ray_stash = (float*)(smem + kLdsBytes + kStashBytes) + wave * 8;
+        if (kHalf && lane == 0) {
+            *(f32x4*)ray_stash = f32x4{ray.o[0], ray.o[1], ray.o[2], ray.d[0]};
+            ray_stash[4] = ray.d[1];
+            ray_stash[5] = ray.d[2];
+        }
 
         const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
         const int c_end = kTrain ? c_begin + 1 : chunks;
@@ -580,6 +594,11 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             const bool ok = s < P;
             const int64_t tile = slot * chunks + c;         // chunk index in the workspace
             const int64_t sp = tile * 16 + j;               // padded sample index
+            if (kHalf) {                                    // the wave's ray, back from LDS (broadcast)
+                const f32x4 r0 = *(const f32x4*)ray_stash;
+                ray.o[0] = r0.x, ray.o[1] = r0.y, ray.o[2] = r0.z, ray.d[0] = r0.w;
+                ray.d[1] = ray_stash[4], ray.d[2] = ray_stash[5];
+            }
             const float t0 = fencepost(a, local, s);
             const float t1 = fencepost(a, local, s + 1);
             const float t2 = fencepost(a, local, s + 2);
@@ -611,6 +630,8 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
                 const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
                                   (float)(1 << (kWScaleLog2 + kXScaleLog2));
+                *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
+                *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
                 load_bias16(small, g, Y);
@@ -635,6 +656,11 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 layer_out_h(pipe, Y, out, norm);
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2)));
+                {
+                    const f32x4 s0 = *(const f32x4*)stash, s1 = *(const f32x4*)(stash + 4);
+                    racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
+                    racc.seg_m = s1.x, racc.seg_s = s1.y, dist = s1.z;
+                }
             } else {
             Moments mom;
             // ---- layer 0: 96 -> 256 ----
@@ -685,9 +711,13 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 }
                 if (g == 0) {
                     if (a.out_mean != nullptr) {
-                        a.out_mean[smp * 3 + 0] = gs.mean[0];
-                        a.out_mean[smp * 3 + 1] = gs.mean[1];
-                        a.out_mean[smp * 3 + 2] = gs.mean[2];
+                        // recomputed (same operations, same bits) rather than kept live across the MLP
+                        const Gaussian gm = kHalf ? frustum(ray, fencepost(a, local, s), fencepost(a, local, s + 1),
+                                                            a.base_radius_sq)
+                                                  : gs;
+                        a.out_mean[smp * 3 + 0] = gm.mean[0];
+                        a.out_mean[smp * 3 + 1] = gm.mean[1];
+                        a.out_mean[smp * 3 + 2] = gm.mean[2];
                     }
                     if (a.out_weights != nullptr) a.out_weights[smp] = w;
                 }
@@ -928,7 +958,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true, false>, kLdsBytes, device,
                                          &done_train);
     if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, true>, kLdsBytes, device,
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, true>, kLdsBytesHalf, device,
                                          &done_half);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64 KiB LDS, <= 256 VGPRs)
@@ -940,7 +970,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
     } else if (a.precision == NERF_HIP_PRECISION_F16X3)
-        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, true>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, true>), dim3((unsigned)grid), dim3(256), kLdsBytesHalf, st, ka);
     else
         hipLaunchKernelGGL((nerf_render_fwd_kernel<false, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
