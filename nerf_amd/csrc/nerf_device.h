@@ -93,20 +93,25 @@ struct WeightPipe {
             // the MFMAs that consume them.  The DMA's own completion is tracked by hand anyway
             // (open_stage: vmcnt(4) + barrier); DMA ops the compiler does not know about only make
             // its own vmcnt waits more conservative, never too weak (vector memory returns in order).
-            const char* src = blob + (size_t)issue_stage * kStageBytes + wave * 4096 + lane * 16;
             const uint32_t dst = (uint32_t)(uintptr_t)(ring + issue_slot * kStageBytes + wave * 4096);
             uint32_t m0_saved;
+            // scalar base (uniform: image + stage + wave) + one 32-bit lane offset
+            const char* base = blob + (size_t)issue_stage * kStageBytes + wave * 4096;
+            const uint64_t base_u = (uint64_t)(uintptr_t)base;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+            const uint64_t sbase = ((uint64_t)hi << 32) | lo;
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %2\n\t"
                 "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                "global_load_lds_dwordx4 %1, %3\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(m0_saved)
-                : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                : "v"(lane * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase)
                 : "memory");
         }
         issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;

@@ -375,7 +375,7 @@ __device__ __forceinline__ void interleave_2() {
 // (vmcnt wait, barrier, DMA issue) therefore sits kSets - 1 units before the stage's first MFMA;
 // at that barrier every wave has issued AND retired (lgkmcnt(0)) all reads of the stage it is
 // still computing on, whose slot the DMA issued next overwrites.
-constexpr int kSets = 4;
+constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unroller (dynamic register indexing)
 
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
