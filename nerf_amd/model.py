@@ -240,6 +240,22 @@ class NeRF(nn.Module):
             self._packed, self._packed_key = packed, key
         return self._packed
 
+    def _check_f16x3_range(self):
+        """The split-precision kernel holds 2^8 * w and 2^4 * relu(gamma * x_hat + beta) as f16
+        pairs (|x_hat| < 16 for 256 features); refuse parameters that would leave the f16 range
+        instead of saturating silently.  Checked once per parameter version."""
+        key = self._packed_key
+        if getattr(self, "_f16x3_checked", None) == key:
+            return
+        heads = self.prediction_heads
+        w_max = max(float(heads[i].weight.detach().abs().max()) for i in (0, 3, 6, 9, 12, 15))
+        act_max = max(16.0 * float(heads[i].weight.detach().abs().max()) + float(heads[i].bias.detach().abs().max())
+                      for i in (1, 4, 7, 10, 13))
+        if w_max * 256.0 >= 65504.0 or act_max * 16.0 >= 65504.0:
+            raise ValueError(f"nerf_amd: parameters out of range for precision='f16x3' (max |w| {w_max:.3g}, "
+                             f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
+        self._f16x3_checked = key
+
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
                    cameras=None, ray_begin=0, t_values=None, u=None, noise=None,
                    density_noise_std=0.0, rng_mode=0, rng_state=None, packed=None, rgb=None, seg=None,
@@ -267,6 +283,8 @@ class NeRF(nn.Module):
         if self.precision not in _lib.PRECISIONS:
             raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
         args.precision = 0 if train_workspace is not None else _lib.PRECISIONS[self.precision]
+        if args.precision == _lib.PRECISIONS["f16x3"]:
+            self._check_f16x3_range()
 
     def _scratch(self, nbytes, device):
         """Cached scratch buffer for the backward's partial slabs."""

@@ -283,3 +283,37 @@ def test_many_samples_per_ray(dev):
     ok = stable_rays(st["density"][:, -1, 0])
     assert (rgb[:, 0].cpu() - ref_rgb)[ok].abs().max() <= 2e-5
     assert (seg[:, 0].cpu() - ref_seg)[ok].abs().max() <= 2e-4
+
+
+def test_f16x3_range_guard_and_training_stays_fp32(dev, precision):
+    """precision='f16x3' refuses parameters outside the f16 range of its scaled operands, and does
+    not touch training: a forward that records a backward runs the fp32 kernels whatever the
+    attribute says (bitwise the same loss and gradients)."""
+    from nerf_amd import NeRF
+    if precision != "f16x3":
+        pytest.skip("f16x3 only")
+    model = make_model(dev, 3.0)
+    with torch.no_grad():
+        model.prediction_heads[6].weight.mul_(1e4)
+    g = torch.Generator().manual_seed(3)
+    o = torch.randn(32, 3, generator=g).to(dev)
+    d = torch.randn(32, 3, generator=g).to(dev)
+    with pytest.raises(ValueError, match="out of range"):
+        with torch.no_grad():
+            model.render_rays(o, d, 16)
+    model.precision = "fp32"
+    with torch.no_grad():
+        rgb, _ = model.render_rays(o, d, 16)               # the fp32 arithmetic takes them
+    assert torch.isfinite(rgb).all()
+
+    grads = {}
+    for prec in ("fp32", "f16x3"):
+        m = make_model(dev, 3.0)
+        m.precision = prec
+        pixels, seg = m.render_rays(o, d, 24)
+        loss = (pixels ** 2).sum() + 1e-3 * (seg ** 2).sum()
+        loss.backward()
+        grads[prec] = (loss.detach().clone(), [p.grad.clone() for p in m.parameters()])
+    assert torch.equal(grads["fp32"][0], grads["f16x3"][0])
+    for a, b in zip(grads["fp32"][1], grads["f16x3"][1]):
+        assert torch.equal(a, b)
