@@ -1,8 +1,15 @@
-"""Timings of the other BASELINE.json configurations on one GPU (for DESIGN.md; not the bench line)."""
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
-from nerf_amd import NeRF
+"""Timings of the other BASELINE.json configurations on one GPU (for DESIGN.md; not the bench line).
+usage: python scripts/bench_configs.py [fp32|f16x3]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerf_amd import NeRF as _NeRF
 import bench
+PRECISION = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+def NeRF(**kw):
+    m = _NeRF(**kw)
+    m.precision = PRECISION
+    return m
+print("precision", PRECISION)
 dev = torch.device('cuda:0')
 def timeit(fn, n=5, w=2):
     for _ in range(w): fn()
