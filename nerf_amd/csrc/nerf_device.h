@@ -274,17 +274,41 @@ __device__ __forceinline__ float row_suffix_sum(float v) {
 __device__ __forceinline__ float row_shift_up(float fill, float v) { return dpp<0x111>(fill, v); }    // from j-1
 __device__ __forceinline__ float row_shift_down(float fill, float v) { return dpp<0x101>(fill, v); }  // from j+1
 
+// Reductions over the 4 lane groups of a sample (lanes j, j+16, j+32, j+48) with the gfx950 row
+// swaps instead of ds_bpermute: v_permlane16_swap exchanges the odd rows of its first operand with
+// the even rows of its second, v_permlane32_swap the upper half with the lower half, so with both
+// operands = v the two results hold (even-row value, odd-row value) resp. (lower-half value,
+// upper-half value) in every lane — no LDS round trip in the exposed LayerNorm / softmax chains.
+// (Inline asm: hipcc 7.2 miscompiles the sum of the two results of
+// __builtin_amdgcn_permlane16_swap / _permlane32_swap into r0 + r0.  The s_nop covers the
+// VALU-write -> permlane-swap wait states the compiler inserts for the builtin.)
+__device__ __forceinline__ void rows_16(float v, float& even, float& odd) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    even = a;
+    odd = b;
+}
+__device__ __forceinline__ void halves_32(float v, float& lower, float& upper) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lower = a;
+    upper = b;
+}
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups of a sample
-    v += xor16(v);
-    v += xor32(v);
-    return v;
+    float a, b;
+    rows_16(v, a, b);
+    v = a + b;
+    halves_32(v, a, b);
+    return a + b;
 }
 __device__ __forceinline__ float group_max(float v) {
-    v = __builtin_fmaxf(v, xor16(v));
-    v = __builtin_fmaxf(v, xor32(v));
-    return v;
+    float a, b;
+    rows_16(v, a, b);
+    v = __builtin_fmaxf(a, b);
+    halves_32(v, a, b);
+    return __builtin_fmaxf(a, b);
 }
 
 // Output slot n = 16 T + 4 g + reg of the padded last layer: 0 density, 1..3 color,
@@ -456,7 +480,13 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
                                                  RayAccum& acc, float* comp) {
 #pragma clang fp contract(off)
     const int j = lane & 15, g = lane >> 4;
-    float dens = __shfl(out[0].x, j);
+    float dens;                                  // out[0].x of lane group 0, to all four groups
+    {
+        float even, odd, lower, upper;
+        rows_16(out[0].x, even, odd);
+        halves_32(even, lower, upper);
+        dens = lower;
+    }
     if (a.noise != nullptr) {
         if (ok) dens = dens + a.noise[local * P + s] * a.density_noise_std;
     } else if (a.rng_mode & 2) {
