@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             ray_stash[4] = ray.d[1];
             ray_stash[5] = ray.d[2];
         }
+        if (kHalf) asm volatile("" ::: "memory");    // the reads of the stash below stay below
 
         const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
         const int c_end = kTrain ? c_begin + 1 : chunks;

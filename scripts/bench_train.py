@@ -1,6 +1,6 @@
 """Timing of one training step (fwd + bwd + Adam) on the GPU: BASELINE config 5 batch shape."""
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF, _lib
 dev = torch.device('cuda:0')
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
@@ -20,5 +20,5 @@ K = 10
 for _ in range(K): l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"train step {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l):.4f}")
+print(f"train step {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l.detach()):.4f}")
 print(f"  algorithmic {3*601088*n*(S-1)/dt/1e12:.1f} TFLOP/s (fwd+dgrad+wgrad)")
