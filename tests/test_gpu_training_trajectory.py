@@ -46,14 +46,14 @@ def test_forty_steps_track_the_cpu_reference_port():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        gpu_losses.append(float(loss))
+        gpu_losses.append(float(loss.detach()))
 
         ref_loss = O.training_loss(ref, cfg, b["rays_o"].cpu(), b["rays_d"].cpu(), S, b["pixels"].cpu(),
                                    u, noise, 1.0)
         ref_opt.zero_grad()
         ref_loss.backward()
         ref_opt.step()
-        cpu_losses.append(float(ref_loss))
+        cpu_losses.append(float(ref_loss.detach()))
 
     gl, cl = torch.tensor(gpu_losses), torch.tensor(cpu_losses)
     assert cl[-1] < 0.5 * cl[0]                                  # it does train
@@ -69,3 +69,13 @@ def test_forty_steps_track_the_cpu_reference_port():
     print(f"held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port {psnr_cpu:.4f} dB; "
           f"max loss deviation {float((gl - cl).abs().max()):.2e}")
     assert abs(psnr_gpu - psnr_cpu) <= 0.01
+
+    # the same trained parameters rendered by the split-precision arithmetic of the inference
+    # kernel: same held-out PSNR (bar: 0.01 dB), same pixels to 1e-4
+    model.precision = "f16x3"
+    with torch.no_grad():
+        render_h, _ = model.render_image(cam_o, cam_r, 16, 16, focal, S)
+    psnr_h = float(O.psnr(render_h.cpu(), truth))
+    print(f"held-out PSNR, f16x3 render of the same parameters: {psnr_h:.4f} dB")
+    assert abs(psnr_h - psnr_cpu) <= 0.01
+    assert (render_h - render).abs().max() <= 1e-4
