@@ -116,7 +116,9 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
     tflops = 3 * FLOP_PER_SAMPLE * rays * (samples - 1) / dt / 1e12
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
-            "tflops_fwd_dgrad_wgrad": tflops, "frac_of_fp32_mfma_peak": tflops / PEAK_TFLOPS_FP32_MFMA}
+            "tflops_fwd_dgrad_wgrad": tflops,
+            "arithmetic": "training forward and data gradient on fp32 MFMA, weight gradient on bf16 "
+                          "triples (six bf16 MFMAs per product, fp32 accumulate)"}
 
 
 def profiled_traffic(precision):

@@ -7,9 +7,12 @@
 //      like the forward, LayerNorm/ReLU backward in registers from the saved x_hat / 1/std.
 //      Writes dY of every layer (row order) for the weight gradients; gamma/beta gradients are
 //      row-reduced by DPP and summed per workgroup in LDS.
-//   2. nerf_wgrad_kernel     — dW_L = dY_L^T X_L as a split-K fp32 MFMA (32x32x2) GEMM over the
-//      padded samples; operands are staged [sample][feature] tiles moved by LDS-DMA; each
-//      workgroup writes a partial slab (and the bias partial = column sums of dY).
+//   2. nerf_wgrad_kernel     — dW_L = dY_L^T X_L as a split-K MFMA GEMM over the padded samples;
+//      operands are staged [sample][feature] fp32 tiles moved by LDS-DMA and split in registers
+//      into bf16 triples (24 significand bits, fp32 exponent range), six
+//      v_mfma_f32_32x32x16_bf16 per product with fp32 accumulation (the exact-fp32 32x32x2 form is
+//      kept behind -DNERF_WGRAD_FP32); each workgroup writes a partial slab (and the bias partial
+//      = column sums of dY).
 //   3. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
 //      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
 #include "nerf_device.h"
@@ -489,6 +492,270 @@ __device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const 
     if ((int)threadIdx.x < Sh::kOutW) slab[b_off + threadIdx.x] = bias_sum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
+// bits, by truncation, and bf16 has fp32's exponent range, so gradients of any magnitude are
+// represented exactly — an f16 pair would need a data-dependent scale for dY) and six
+// v_mfma_f32_32x32x16_bf16 per product: hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi, fp32
+// accumulate; the dropped terms are <= 2^-24 relative.  16 samples per MFMA instead of 2:
+// 96 x 32 cycles per 16 samples against 128 x 64.
+//   A operand: lane l holds dY[sample 8 (l >> 5) + jj][out row l & 31], jj = 0..7
+//   B operand: lane l holds  X[sample 8 (l >> 5) + jj][in  col l & 31]
+//   C/D: as v_mfma_f32_32x32x2_f32 (the epilogue and the reduce kernel do not change)
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Bf3 {
+    bf8 h, m, l;
+};
+
+// eight fp32 values -> their (hi, mid, lo) bf16 truncations, element jj = value jj
+__device__ __forceinline__ Bf3 split_bf3(const float (&x)[8]) {
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = x[2 * p + e];
+            hb[e] = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+            const float r1 = v - __builtin_bit_cast(float, hb[e]);          // exact
+            mb[e] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, mb[e]);         // exact
+            lb[e] = __builtin_bit_cast(unsigned, r2);
+        }
+        // upper halves of (value 2p, value 2p + 1) -> one dword, value 2p in the low half
+        ph[p] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+        pm[p] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+        pl[p] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+    }
+    Bf3 r;
+    r.h = __builtin_bit_cast(bf8, ph);
+    r.m = __builtin_bit_cast(bf8, pm);
+    r.l = __builtin_bit_cast(bf8, pl);
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(const bf8& a, const bf8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <class Sh, bool kAffine>
+__device__ __forceinline__ void wgrad_body_bf16(const BwdArgs& ba, char* smem, const float* dy, const float* x,
+                                                const float* small_prev, int w_off, int b_off, int split) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int out0, in0;                                // first 32-wide tile of this wave
+    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
+    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
+    else { out0 = 0; in0 = 2 * wave; }
+
+    float ga[Sh::kTi], be[Sh::kTi];
+#pragma unroll
+    for (int b = 0; b < Sh::kTi; ++b) {
+        const int f = 32 * (in0 + b) + (lane & 31);
+        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
+        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
+        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
+    }
+
+    f32x16 acc[Sh::kTo][Sh::kTi];
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // bias gradient = column sums of dY: summed from the A-operand values as they are converted
+    // (every dY element of the wave's out tiles passes through exactly once per tile); waves that
+    // share their out tiles with another wave leave it to the one with in0 == 0
+    float bsum[Sh::kTo];
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a) bsum[a] = 0.f;
+
+    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
+    int64_t tile_end = tile_begin + ba.tiles_per_split;
+    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
+    const int64_t nt = tile_end > tile_begin ? tile_end - tile_begin : 0;
+    const int i = lane & 31, kk = lane >> 5;
+    constexpr int kSteps = kKs / 16;              // MFMA k-steps per LDS tile
+    // the next tile's DMA pieces go out in the FIRST HALF of this tile's slots, so that the last of
+    // them has half a tile of MFMAs to land before the tile hand-over waits for it
+    constexpr int kIssueSlots = kSteps * Sh::kTo / 2;
+    constexpr int kPerSlot = (Sh::kPiecesPerWave + kIssueSlots - 1) / kIssueSlots;
+
+    if (nt > 0) wgrad_issue<Sh>(dy, x, tile_begin * kKs, smem, wave, lane);
+    for (int64_t k = 0; k < nt; ++k) {
+        char* cur = smem + (k & 1) * Sh::kTileBytes;
+        char* nxt_buf = smem + ((k + 1) & 1) * Sh::kTileBytes;
+        const bool more = k + 1 < nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* dyt = (const float*)cur;
+        const float* xt = (const float*)(cur + Sh::kDyBytes);
+        auto b_terms = [&](int step, int b) {     // relu(gamma x_hat + beta) (or the encoded inputs), split
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float raw = xt[(16 * step + 8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
+                v[jj] = kAffine ? __builtin_fmaxf(__builtin_fmaf(raw, ga[b], be[b]), 0.f) : raw;
+            }
+            return split_bf3(v);
+        };
+        auto a_terms = [&](int step, int a) {
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                v[jj] = dyt[(16 * step + 8 * kk + jj) * Sh::kOutW + 32 * (out0 + a) + i];
+                bsum[a] += v[jj];
+            }
+            return split_bf3(v);
+        };
+        // Software pipeline over the tile's kSteps x kTo slots: while the 6 kTi MFMAs of slot
+        // (step, a) issue, the VALU converts the A operand of the next slot and this slot's share of
+        // the next k-step's B operands, one value (or two) behind each MFMA — spelled out MFMA by
+        // MFMA with scheduling fences, because the scheduler otherwise clumps every conversion in
+        // front of the MFMA batch (one wave per SIMD here: nothing else would fill the matrix pipe
+        // meanwhile).  Exposed per tile: the first k-step's B operands and the first A operand.
+        Bf3 bt[Sh::kTi], bn[Sh::kTi];
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b) bt[b] = b_terms(0, b);
+        Bf3 at = a_terms(0, 0), an;
+        constexpr int kBPerSlot = (Sh::kTi + Sh::kTo - 1) / Sh::kTo;
+        constexpr int kMfmas = 6 * Sh::kTi;                       // per slot
+        constexpr int kValues = 8 * (1 + kBPerSlot);              // values converted per slot
+        constexpr int kLead = kMfmas / 6;       // MFMAs issued before the first conversion (the slot's
+                                                // LDS reads land under them)
+        constexpr int kItems = 10 * (1 + kBPerSlot);              // 8 values + 2 packing items per operand
+#pragma unroll
+        for (int step = 0; step < kSteps; ++step) {
+#pragma unroll
+            for (int a = 0; a < Sh::kTo; ++a) {
+                const bool last_slot = step == kSteps - 1 && a == Sh::kTo - 1;
+                const bool next_b = step + 1 < kSteps;
+                // the next tile's LDS-DMA pieces, a few per slot
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < kPerSlot; ++q) {
+                        const int piece = (step * Sh::kTo + a) * kPerSlot + q;
+                        if (piece < Sh::kPiecesPerWave)
+                            wgrad_issue_piece<Sh>(dy, x, (tile_begin + k + 1) * kKs, nxt_buf, wave, lane, piece);
+                    }
+                }
+                // raw operands of what this slot converts (LDS reads issued up front)
+                float raw[1 + kBPerSlot][8];
+                const int na = a + 1 < Sh::kTo ? a + 1 : 0, ns = a + 1 < Sh::kTo ? step : step + 1;
+                if (!last_slot) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        raw[0][jj] = dyt[(16 * ns + 8 * kk + jj) * Sh::kOutW + 32 * (out0 + na) + i];
+                }
+                if (next_b) {
+#pragma unroll
+                    for (int q = 0; q < kBPerSlot; ++q) {
+                        const int b = a * kBPerSlot + q;
+                        if (b < Sh::kTi) {
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj)
+                                raw[1 + q][jj] = xt[(16 * (step + 1) + 8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
+                        }
+                    }
+                }
+                unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
+                u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < kMfmas; ++m) {
+                    const int b = m / 6, t = m % 6;
+                    const bf8& ta = t == 5 ? at.l : (t == 2 || t == 3 ? at.m : at.h);
+                    const bf8& tb = t == 4 ? bt[b].l : (t == 1 || t == 3 ? bt[b].m : bt[b].h);
+                    acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // This MFMA's share of the slot's conversions.  Work items, per operand: its 8
+                    // values (one dependent chain of ~5-7 VALU each), then two items of 6 byte-permutes
+                    // that pack the halves; spread evenly over the MFMAs behind the first kLead (whose
+                    // shadow covers the latency of the slot's LDS reads).  One wave per SIMD: an MFMA
+                    // can only start when the VALU work in front of it is done, so every gap must
+                    // stay under one MFMA (32 cycles ~ 6-7 VALU), not just the average.
+#pragma unroll
+                    for (int it = 0; it < kItems; ++it) {
+                        if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
+                        const int op = it / 10, w = it % 10;       // op 0: next A tile, 1..: B tiles
+                        const int bq = a * kBPerSlot + (op - 1);
+                        const bool live = op == 0 ? !last_slot : (next_b && bq < Sh::kTi);
+                        if (!live) continue;
+                        if (w < 8) {
+                            float val = raw[op][w];
+                            // (volatile asm in and out: plain arithmetic floats across the
+                            // scheduling fences, these two pin the value's conversion to this gap)
+                            asm volatile("" : "+v"(val));
+                            if (op > 0 && kAffine) val = __builtin_fmaxf(__builtin_fmaf(val, ga[bq], be[bq]), 0.f);
+                            if (op == 0) bsum[na] += val;
+                            th[op][w] = __builtin_bit_cast(unsigned, val) & 0xffff0000u;
+                            const float r1 = val - __builtin_bit_cast(float, th[op][w]);
+                            tm[op][w] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+                            tl[op][w] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, tm[op][w]));
+                            asm volatile("" : "+v"(tl[op][w]));
+                        } else {
+#pragma unroll
+                            for (int p = 2 * (w - 8); p < 2 * (w - 8) + 2; ++p) {
+                                unsigned lo_h = th[op][2 * p], lo_m = tm[op][2 * p], lo_l = tl[op][2 * p];
+                                asm volatile("" : "+v"(lo_h), "+v"(lo_m), "+v"(lo_l));
+                                ph[op][p] = __builtin_amdgcn_perm(th[op][2 * p + 1], lo_h, 0x07060302u);
+                                pm[op][p] = __builtin_amdgcn_perm(tm[op][2 * p + 1], lo_m, 0x07060302u);
+                                pl[op][p] = __builtin_amdgcn_perm(tl[op][2 * p + 1], lo_l, 0x07060302u);
+                                asm volatile("" : "+v"(ph[op][p]), "+v"(pm[op][p]), "+v"(pl[op][p]));
+                            }
+                            if (w == 9) {
+                                Bf3 r;
+                                r.h = __builtin_bit_cast(bf8, ph[op]);
+                                r.m = __builtin_bit_cast(bf8, pm[op]);
+                                r.l = __builtin_bit_cast(bf8, pl[op]);
+                                if (op == 0) an = r;
+                                else bn[bq] = r;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!last_slot) at = an;
+            }
+            if (step + 1 < kSteps) {
+#pragma unroll
+                for (int b = 0; b < Sh::kTi; ++b) bt[b] = bn[b];
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r];
+            }
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a) {
+        const float both = bsum[a] + __shfl_xor(bsum[a], 32);       // the two 8-sample halves of a k-step
+        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both;
+    }
+}
+
+#ifdef NERF_WGRAD_FP32       /* the exact-fp32 32x32x2 GEMM (kept as the comparison build) */
+#define WGRAD_BODY wgrad_body
+#else
+#define WGRAD_BODY wgrad_body_bf16
+#endif
+
 // All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
 // layer-0 / layer-5 jobs fill the tail instead of running half-empty launches of their own.
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
@@ -497,14 +764,14 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;       // [layer][bias | gamma | beta][256]
     if (job < 4) {                                // layers 1..4: input = LayerNorm+ReLU of layer job
-        wgrad_body<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+        WGRAD_BODY<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
                                    ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
                                    small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
                                    kSlabB + (job + 1) * kHidden, split);
     } else if (job == 4) {                        // layer 0: input = encoded features
-        wgrad_body<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
+        WGRAD_BODY<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
     } else {                                      // layer 5: input = LayerNorm+ReLU of layer 4
-        wgrad_body<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+        WGRAD_BODY<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
                                   kSlabW5, kSlabB + 5 * kHidden, split);
     }
 }

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nerf_amd import build as B
 variants = [("base", [])]
+RAYS = os.environ.get("ABLATE_RAYS", "4096")
 for arg in sys.argv[1:]:
     name, _, defs = arg.partition("=")
     variants.append((name, [d for d in defs.split(",") if d]))
@@ -13,9 +14,9 @@ for name, defs in variants:
     d = f"/tmp/abl_{name}"
     env = dict(os.environ, NERF_HIP_LIB=out, TMPDIR="/tmp")
     subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
-                    "python3", os.path.join(ROOT, "scripts", "bench_train.py"), "4096"], env=env, cwd="/tmp",
+                    "python3", os.path.join(ROOT, "scripts", "bench_train.py"), RAYS], env=env, cwd="/tmp",
                    capture_output=True, text=True)
-    f = glob.glob(d + "/*/*kernel_stats.csv")
+    f = glob.glob(d + "/*/*kernel_stats.csv") + glob.glob(d + "/*kernel_stats.csv")
     row = {}
     for r in csv.DictReader(open(f[0])):
         for key in ("bwd_data", "render_fwd", "wgrad", "reduce"):
