@@ -67,7 +67,7 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     args.n_rays = 0                       # empty batch is a no-op, not an error
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == 0
-    # unknown precision / split precision on the training forward: refused before any HIP call
+    # unknown precision: refused before any HIP call
     dummy = ctypes.c_void_p(16)
     args = _lib.RenderArgs()
     args.n_rays, args.num_samples = 8, 4
@@ -75,9 +75,6 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     args.precision = 7
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     assert b"precision" in handle.nerf_hip_last_error()
-    args.precision, args.train_workspace = _lib.PRECISIONS["f16x3"], dummy
-    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
-    assert b"fp32 only" in handle.nerf_hip_last_error()
     assert handle.nerf_hip_pack_weights(None, None, None) == -1
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()
@@ -128,7 +125,9 @@ def test_host_helpers_match_reference_fixtures():
     assert torch.equal(t[1], g["t64"])
     g1 = load_golden("g1_stages")
     w = NeRF.alpha_compositing_coefficients(g1["means"], g1["density"])
-    assert torch.equal(w, g1["weights"])
+    # (exp / cumprod on the host: identical on the machine that made the fixture, last-bit
+    #  differences between CPU models)
+    assert (w - g1["weights"]).abs().max() <= 1e-7
 
 
 def test_no_cpu_fallback():
