@@ -11,7 +11,7 @@ deterministic fenceposts, RGB + 50-class segmentation composited): the whole hot
 N poses one frame each with no data-path collective ("weak" scaling; ``--scaling strong`` splits
 ONE frame into row blocks instead).  Rank 0 prints one JSON line.
 
-Two arithmetics of the same kernel (NerfHipRenderArgs.precision, DESIGN.md section 9), both held to
+Two arithmetics of the same kernel (NerfHipRenderArgs.precision, DESIGN.md section 3b), both held to
 the same parity tests: "f16x3" (default here: every fp32 product as three f16 MFMAs with fp32
 accumulation, v_mfma_f32_16x16x32_f16) and "fp32" (exact-fp32 v_mfma_f32_16x16x4_f32).  The
 headline `value` is the selected precision's; at N=1 the other one is measured in the same run and
