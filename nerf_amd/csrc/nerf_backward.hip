@@ -626,7 +626,6 @@ __device__ __forceinline__ void wgrad_body_bf16(const BwdArgs& ba, char* smem, c
         Bf3 at = a_terms(0, 0), an;
         constexpr int kBPerSlot = (Sh::kTi + Sh::kTo - 1) / Sh::kTo;
         constexpr int kMfmas = 6 * Sh::kTi;                       // per slot
-        constexpr int kValues = 8 * (1 + kBPerSlot);              // values converted per slot
         constexpr int kLead = kMfmas / 6;       // MFMAs issued before the first conversion (the slot's
                                                 // LDS reads land under them)
         constexpr int kItems = 10 * (1 + kBPerSlot);              // 8 values + 2 packing items per operand
