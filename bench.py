@@ -88,13 +88,12 @@ def cpu_baseline(rows=32):
                       f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
 
 
-def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32"):
+def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
     """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
     backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
     from nerf_amd import NeRF
     torch.manual_seed(0)
     model = NeRF().to(dev)
-    model.train_precision = train_precision
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)
@@ -118,8 +117,8 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
-            "arithmetic": f"training forward {train_precision}, data gradient on fp32 MFMA, weight "
-                          "gradient on bf16 triples (six bf16 MFMAs per product, fp32 accumulate)"}
+            "arithmetic": "training forward and data gradient on fp32 MFMA, weight gradient on bf16 "
+                          "triples (six bf16 MFMAs per product, fp32 accumulate)"}
 
 
 def profiled_traffic(precision):
@@ -292,8 +291,7 @@ def main():
                 "roofline": roofline(other, rays_per_rank, o_kernel_ms, o_launches, True),
             }
         if world == 1 and not args.no_cpu_baseline:
-            line["train_step"] = train_step_timing(dev)                       # class defaults
-            line["train_step_f16x3_forward"] = train_step_timing(dev, train_precision="f16x3")
+            line["train_step"] = train_step_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if distributed:

@@ -126,21 +126,9 @@ struct WeightPipe {
     // slot the next issue() overwrites: write-after-read safe without any timing argument.
     // The caller reads its first operands, THEN calls issue(): the reads' latency hides under the
     // previous stage's trailing MFMAs instead of behind the DMA address arithmetic.
-    // kYounger: vector-memory operations (x_hat stores of the training forward) that this wave is
-    // KNOWN to have issued after the DMA of the stage being opened, besides the 4 pieces of the
-    // following stage.  vmcnt counts loads, stores and LDS-DMA together in issue order, so without
-    // it the wait also covers those stores (an HBM write latency per stage, which a split-precision
-    // stage is too short to hide); an under-count only makes the wait stricter, an over-count would
-    // let the stage be read before it has landed.
-    template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
 #ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
-        static_assert(kYounger >= 0 && kYounger <= 4, "vmcnt immediate");
-        if (kYounger == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 #endif
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();

@@ -138,8 +138,7 @@ __device__ __forceinline__ void interleave_7() {
 template <bool kTrain, class Mom>
 __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
-                                                   float* save_rstd, float eps = 1e-5f,
-                                                   float save_scale = 1.0f) {
+                                                   float* save_rstd, float eps = 1e-5f) {
     const float mean = group_sum(m.sum()) * (1.0f / 256.0f);
     const float ex2 = group_sum(m.sum_sq()) * (1.0f / 256.0f);
     float var = ex2 - mean * mean;
@@ -158,7 +157,7 @@ __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&r
     const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-    if (kTrain && g == 0) *save_rstd = rstd * save_scale;
+    if (kTrain && g == 0) *save_rstd = rstd;
     LazyNorm n;
     n.rstd = rstd;
     n.shift = -mean * rstd;
@@ -290,7 +289,7 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-precision ("f16x3") layers of the forward (inference, and the training forward on request): every fp32 operand is an f16 pair
+// Split-precision ("f16x3") layers of the inference path: every fp32 operand is an f16 pair
 // (hi, lo) and a product is three v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi, fp32
 // accumulate; the dropped lo.lo term is ~2^-22 relative), 5.3x the fp32-MFMA rate per product.
 // Image and scalings: nerf_layout.h.  A k block m = register tiles 2m, 2m+1 of the input; its
@@ -381,14 +380,14 @@ constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unrolle
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
 // built (normalise tile by tile, then split) during stage (0, m).
-template <int KB, bool kNormIn, bool kTrain>
+template <int KB, bool kNormIn>
 __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
                                               const LazyNorm& norm, HMoments& mom) {
     constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
     h8 bhi[KB], blo[KB];
     if (kNormIn) {
-        normalize_tile<kTrain, kPackNorm>(in[0], norm, 0);
-        normalize_tile<kTrain, kPackNorm>(in[1], norm, 1);
+        normalize_tile<false, kPackNorm>(in[0], norm, 0);
+        normalize_tile<false, kPackNorm>(in[1], norm, 1);
     }
     split8(in[0], in[1], bhi[0], blo[0]);
     mom.reset();
@@ -416,15 +415,7 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
             __builtin_amdgcn_sched_barrier(0);
             if (U + kSets - 1 < kUnits) {
                 const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
-                if (ip == 0) {
-                    // training: the x_hat stores of this stage (units 1 and 3, before this hand-over)
-                    // and of the previous one are younger than the DMA of the stage being opened
-                    constexpr bool kStores = kTrain && kNormIn;
-                    const bool mine = kStores && build_next, prev = kStores && s >= 1 && s - 1 < KB - 1;
-                    if (mine && prev) st = (const h8*)pipe.template open_stage<4>();
-                    else if (mine || prev) st = (const h8*)pipe.template open_stage<2>();
-                    else st = (const h8*)pipe.open_stage();
-                }
+                if (ip == 0) st = (const h8*)pipe.open_stage();
                 ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
                 al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
                 if (ip == 0) pipe.prefetch_next();
@@ -438,9 +429,9 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
             out[T] = mfma_h(al[set], bhi[m], out[T]);
             // VALU riding in the shadow of this unit's MFMAs
             if (build_next) {
-                if (kNormIn && i == 1) normalize_tile<kTrain, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (kNormIn && i == 1) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
                 if (i == 2) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
-                if (kNormIn && i == 3) normalize_tile<kTrain, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (kNormIn && i == 3) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
                 if (i == 4) {
                     split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
                     bhi[m + 1] = join8(nh[0], nh[1], nh[2], nh[3]);
@@ -472,13 +463,12 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
 
 // Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
 // block m + 1 is built during the four units of block m.
-template <bool kTrain>
 __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
                                             const LazyNorm& norm) {
     constexpr int kUnits = 8 * kStagesL5;
     h8 bh[2], bl[2];
-    normalize_tile<kTrain, kPackNorm>(in[0], norm, 0);
-    normalize_tile<kTrain, kPackNorm>(in[1], norm, 1);
+    normalize_tile<false, kPackNorm>(in[0], norm, 0);
+    normalize_tile<false, kPackNorm>(in[1], norm, 1);
     split8(in[0], in[1], bh[0], bl[0]);
     h8 ah[kSets], al[kSets];
     f32x4 ga = norm.gam[2], be = norm.bet[2];
@@ -520,9 +510,9 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
             acc[T] = mfma_h(ah[set], bl[pb], acc[T]);
             acc[T] = mfma_h(al[set], bh[pb], acc[T]);
             if (m + 1 < 8) {
-                if (q == 0) normalize_tile<kTrain, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (q == 0) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
                 if (q == 1) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
-                if (q == 2) normalize_tile<kTrain, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (q == 2) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
                 if (q == 3) {
                     split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
                     bh[pb ^ 1] = join8(nh[0], nh[1], nh[2], nh[3]);
@@ -541,6 +531,7 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
 // ---------------------------------------------------------------------------------------------
 template <bool kTrain, bool kHalf>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
+    static_assert(!(kTrain && kHalf), "the split-precision path is inference only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -590,12 +581,12 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
         racc.reset();
         float* const stash = (float*)(smem + kLdsBytes) + (wave * 64 + lane) * kStashFloatsPerLane;
         float* const ray_stash = (float*)(smem + kLdsBytes + kStashBytes) + wave * 8;
-        if (kHalf && !kTrain && lane == 0) {     // (a training item is one chunk: nothing to park)
+        if (kHalf && lane == 0) {
             *(f32x4*)ray_stash = f32x4{ray.o[0], ray.o[1], ray.o[2], ray.d[0]};
             ray_stash[4] = ray.d[1];
             ray_stash[5] = ray.d[2];
         }
-        if (kHalf && !kTrain) asm volatile("" ::: "memory");    // the reads of the stash below stay below
+        if (kHalf) asm volatile("" ::: "memory");    // the reads of the stash below stay below
 
         const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
         const int c_end = kTrain ? c_begin + 1 : chunks;
@@ -604,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             const bool ok = s < P;
             const int64_t tile = slot * chunks + c;         // chunk index in the workspace
             const int64_t sp = tile * 16 + j;               // padded sample index
-            if (kHalf && !kTrain) {                         // the wave's ray, back from LDS (broadcast)
+            if (kHalf) {                                    // the wave's ray, back from LDS (broadcast)
                 const f32x4 r0 = *(const f32x4*)ray_stash;
                 ray.o[0] = r0.x, ray.o[1] = r0.y, ray.o[2] = r0.z, ray.d[0] = r0.w;
                 ray.d[1] = ray_stash[4], ray.d[2] = ray_stash[5];
@@ -640,40 +631,33 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
                 const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
                                   (float)(1 << (kWScaleLog2 + kXScaleLog2));
-                // x_hat is scale-free; the saved 1/std is the one of the unscaled activations
-                const float rs = (float)(1 << (kWScaleLog2 + kXScaleLog2));
-                if (!kTrain) {
-                    *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
-                    *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
-                }
+                *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
+                *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
                 load_bias16(small, g, Y);
-                layer_fused_h<3, false, kTrain>(pipe, X, Y, norm, mom);
-                norm = finish_moments<kTrain, HMoments>(mom, Y, small, g, xrow + ka.save.xhat[0],
-                                                        rstd_p + ka.save.rstd[0], eps, rs);
+                layer_fused_h<3, false>(pipe, X, Y, norm, mom);
+                norm = finish_moments<false, HMoments>(mom, Y, small, g, nullptr, nullptr, eps);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
                     const float* small_a = small + L * kSmallPerLayer;
                     load_bias16(small_a, g, X);
-                    layer_fused_h<8, true, kTrain>(pipe, Y, X, norm, mom);
-                    norm = finish_moments<kTrain, HMoments>(mom, X, small_a, g, xrow + ka.save.xhat[L],
-                                                            rstd_p + ka.save.rstd[L], eps, rs);
+                    layer_fused_h<8, true>(pipe, Y, X, norm, mom);
+                    norm = finish_moments<false, HMoments>(mom, X, small_a, g, nullptr, nullptr, eps);
                     const float* small_b = small_a + kSmallPerLayer;
                     load_bias16(small_b, g, Y);
-                    layer_fused_h<8, true, kTrain>(pipe, X, Y, norm, mom);
-                    norm = finish_moments<kTrain, HMoments>(mom, Y, small_b, g, xrow + ka.save.xhat[L + 1],
-                                                            rstd_p + ka.save.rstd[L + 1], eps, rs);
+                    layer_fused_h<8, true>(pipe, X, Y, norm, mom);
+                    norm = finish_moments<false, HMoments>(mom, Y, small_b, g, nullptr, nullptr, eps);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
 #pragma unroll
                     for (int T = 0; T < 4; ++T) out[T] = b[T];
                 }
-                layer_out_h<kTrain>(pipe, Y, out, norm);
+                layer_out_h(pipe, Y, out, norm);
 #pragma unroll
-                for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / rs);
-                if (!kTrain) {
+                for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2)));
+                {
                     const f32x4 s0 = *(const f32x4*)stash, s1 = *(const f32x4*)(stash + 4);
                     racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
                     racc.seg_m = s1.x, racc.seg_s = s1.y, dist = s1.z;
@@ -955,6 +939,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     const bool train = a.train_workspace != nullptr;
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
+    if (train && a.precision != NERF_HIP_PRECISION_FP32)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: the training forward is fp32 only");
     if (train && (a.out_raw != nullptr || a.out_mean != nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean are not produced by the training forward");
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave
@@ -966,10 +952,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static unsigned done_infer = 0, done_train = 0, done_half = 0, done_train_half = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true, true>, kLdsBytesHalf, device,
-                                         &done_train_half);
-    if (rc) return rc;
+    static unsigned done_infer = 0, done_train = 0, done_half = 0;
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, false>, kLdsBytes, device,
                                          &done_infer);
     if (rc) return rc;
@@ -984,10 +967,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
     if (train) {
-        if (a.precision == NERF_HIP_PRECISION_F16X3)
-            hipLaunchKernelGGL((nerf_render_fwd_kernel<true, true>), dim3((unsigned)grid), dim3(256), kLdsBytesHalf, st, ka);
-        else
-            hipLaunchKernelGGL((nerf_render_fwd_kernel<true, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+        hipLaunchKernelGGL((nerf_render_fwd_kernel<true, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
     } else if (a.precision == NERF_HIP_PRECISION_F16X3)

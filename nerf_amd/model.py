@@ -124,8 +124,6 @@ class NeRF(nn.Module):
         # precision of the MLP in inference launches (anything that does not record a backward):
         # "fp32" = exact-fp32 MFMA, "f16x3" = split-precision f16 MFMA (include/nerf_hip.h).
         self.precision = "fp32"
-        # same choice for the forward of a training step (the launch that records a backward)
-        self.train_precision = "fp32"
         self._packed = None
         self._packed_key = None
         self._tables = {}
@@ -282,10 +280,9 @@ class NeRF(nn.Module):
         args.rgb, args.seg = _lib.ptr(rgb), _lib.ptr(seg)
         args.out_mean, args.out_raw, args.out_weights = _lib.ptr(mean), _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
-        chosen = self.train_precision if train_workspace is not None else self.precision
-        if chosen not in _lib.PRECISIONS:
-            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {chosen!r}")
-        args.precision = _lib.PRECISIONS[chosen]
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        args.precision = 0 if train_workspace is not None else _lib.PRECISIONS[self.precision]
         if args.precision == _lib.PRECISIONS["f16x3"]:
             self._check_f16x3_range()
 

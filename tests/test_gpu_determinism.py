@@ -1,0 +1,35 @@
+"""Run-to-run determinism of the forward launches (no atomics anywhere in the path, so results must
+be bitwise reproducible): both arithmetics of the inference kernel and the training forward, at a
+batch that puts two workgroups on every CU (where a data race between a stage's LDS-DMA and its
+consumers would show) and at a small one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_rays,num_samples", [(256, 100), (4096, 64)])
+@pytest.mark.parametrize("mode", ["infer-fp32", "infer-f16x3", "train-fp32"])
+def test_forward_is_bitwise_reproducible(mode, n_rays, num_samples):
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    with torch.no_grad():
+        for i in (0, 3, 6, 9, 12, 15):
+            model.prediction_heads[i].weight.mul_(2.0)
+    g = torch.Generator().manual_seed(n_rays)
+    o, d = torch.randn(n_rays, 3, generator=g).to(dev), torch.randn(n_rays, 3, generator=g).to(dev)
+    u = torch.rand(n_rays, num_samples, generator=g).to(dev)
+    noise = torch.randn(n_rays, num_samples - 1, 1, generator=g).to(dev)
+    kind, model.precision = mode.split("-")
+    first = None
+    for _ in range(12):
+        with torch.set_grad_enabled(kind == "train"):
+            rgb, seg = model.render_rays(o, d, num_samples, randomly_sample=True, density_noise_std=0.5,
+                                         u=u, noise=noise)
+        cur = torch.cat([rgb.detach().flatten(), seg.detach().flatten()])
+        if first is None:
+            first = cur.clone()
+        else:
+            assert torch.equal(cur, first), float((cur - first).abs().max())

@@ -29,9 +29,8 @@ if __name__ == "__main__":
     ap.add_argument("--log-interval", type=int, default=1000)
     ap.add_argument("--max-iterations", type=int, default=None)
     ap.add_argument("--rng", choices=("torch", "philox"), default="philox")
-    # arithmetic of the MLP in held-out renders / in the forward of a training step
+    # arithmetic of the MLP in the held-out renders; training steps run fp32 / bf16x6
     ap.add_argument("--precision", choices=("fp32", "f16x3"), default="fp32")
-    ap.add_argument("--train-precision", choices=("fp32", "f16x3"), default="fp32")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -49,7 +48,7 @@ if __name__ == "__main__":
                     learning_rate=args.learning_rate, num_samples_per_ray=args.num_samples_per_ray,
                     density_noise_std=args.density_noise_std, log_interval=args.log_interval,
                     rng=args.rng)
-    run.model.precision, run.model.train_precision = args.precision, args.train_precision
+    run.model.precision = args.precision
     run.write_params(vars(args))
     run.fit(epochs=args.epochs, max_iterations=args.max_iterations)
     if run.rank == 0 and run.psnrs:
