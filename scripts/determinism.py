@@ -29,3 +29,19 @@ for n, S in ((256, 100), (130, 64), (4096, 64)):
             elif not torch.equal(cur, first):
                 bad += 1; worst = max(worst, float((cur - first).abs().max()))
         print(f"{n:5d} x {S:3d} {mode:12s}: {bad}/{reps - 1} runs differ, max |diff| {worst:.3g}", flush=True)
+# the bench frame
+import bench
+cam_o, cam_r = bench.look_at(bench.CAMERA)
+cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+m2 = NeRF(focal_length=bench.FOCAL).to(dev)
+for prec in ("fp32", "f16x3"):
+    m2.precision = prec
+    first, bad = None, 0
+    n = max(4, reps // 6)
+    for r in range(n):
+        with torch.no_grad():
+            img, seg = m2.render_image(cam_o, cam_r, 800, 800, bench.FOCAL, 128)
+        cur = torch.cat([img.flatten(), seg.flatten()])
+        if first is None: first = cur.clone()
+        elif not torch.equal(cur, first): bad += 1
+    print(f"800x800x128 frame {prec}: {bad}/{n - 1} runs differ", flush=True)
