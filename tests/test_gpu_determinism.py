@@ -33,3 +33,29 @@ def test_forward_is_bitwise_reproducible(mode, n_rays, num_samples):
             first = cur.clone()
         else:
             assert torch.equal(cur, first), float((cur - first).abs().max())
+
+
+def test_training_step_gradients_are_bitwise_reproducible():
+    """Forward + backward of a 4096 x 64 batch (BASELINE config 5 shape), five times: loss and the
+    flat 304,438-element gradient must not move by a bit."""
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    g = torch.Generator().manual_seed(7)
+    n, S = 4096, 64
+    o, d = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, 3, generator=g).to(dev)
+    u = torch.rand(n, S, generator=g).to(dev)
+    noise = torch.randn(n, S - 1, 1, generator=g).to(dev)
+    target = torch.rand(n, 3, generator=g).to(dev)
+    first = None
+    for _ in range(5):
+        model.zero_grad(set_to_none=True)
+        pixels, seg = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0, u=u, noise=noise)
+        loss = ((pixels - target.unsqueeze(1)) ** 2).mean() + 1e-3 * (seg ** 2).mean()
+        loss.backward()
+        cur = torch.cat([loss.detach().reshape(1)] + [p.grad.flatten() for p in model.parameters()])
+        if first is None:
+            first = cur.clone()
+        else:
+            assert torch.equal(cur, first), float((cur - first).abs().max())
