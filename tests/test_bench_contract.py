@@ -1,0 +1,33 @@
+"""CPU checks of bench.py's reporting helpers (the timed part needs the GPU): the roofline object
+carries every field the contract names for both arithmetics, and the profiled-traffic lookup picks
+the newest committed summary of the right precision."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_roofline_fields_and_arithmetic():
+    import bench
+    rays = 640000
+    for precision, peak, per in (("fp32", 157.3, 1), ("f16x3", 2516.6, 3)):
+        r = bench.roofline(precision, rays, kernel_ms=100.0, launches=5, with_traffic=True)
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in r
+        flop = rays * 127 * bench.FLOP_PER_SAMPLE
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == peak
+        assert abs(r["achieved"] - flop / 0.1 / 1e12) < 1e-9
+        assert abs(r["frac"] - r["achieved"] / peak) < 1e-12
+        assert abs(r["executed_frac"] - per * r["frac"]) < 1e-12
+        assert r["algorithmic_bytes"] == rays * 212 + 48
+        assert r["traffic"] is not None and r["traffic"] < 2 * r["algorithmic_bytes"]
+        assert ("f16x3" in r["traffic_source"]) == (precision == "f16x3")
+        json.dumps(r)
+
+
+def test_bench_constants_match_the_survey():
+    import bench
+    assert bench.FLOP_PER_SAMPLE == 2 * (96 * 256 + 4 * 256 * 256 + 256 * 54)
+    assert (bench.IMAGE, bench.SAMPLES) == (800, 128)
