@@ -23,7 +23,7 @@ using namespace nerf_device;
 namespace {
 
 constexpr int kGbFloats = 5 * 2 * kHidden;                         // gamma/beta partials per workgroup
-constexpr int kBwdLdsBytes = kSmallLdsBytes + kRing * kStageBytes + kGbFloats * 4;   // 74 KiB
+constexpr int kBwdLdsBytes = kRingBytes + kSmallLdsBytes + kGbFloats * 4;   // 74.25 KiB
 constexpr int kMaxSplits = 128;
 constexpr int kMaxDataGrid = 1024;
 
@@ -96,8 +96,8 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
                                                     f32x4 (&acc)[16], float (&act)[64],
                                                     const f32x4 (&xh)[16], float rstd,
                                                     float* dy_row, float* gb_l, GammaBetaTurn& turn) {
-    const f32x4* gam = (const f32x4*)(small_l + kHidden) + g * 16;
-    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
+    const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
+    const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     float s1 = 0.f, s2 = 0.f;
     f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -267,18 +267,16 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     float* const ws = a.train_workspace;
-    float* const gb = (float*)(smem + kSmallLdsBytes + kRing * kStageBytes);
+    float* const gb = (float*)(smem + kRingBytes + kSmallLdsBytes);
 
     {
-        const float* small_g = a.packed + kBlobFloats;
-        float* small_l = (float*)smem;
-        for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
+        stage_small_image(a.packed + kBlobFloats, (float*)(smem + kRingBytes));
         for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
     }
-    const float* small = (const float*)smem;
+    const float* small = (const float*)(smem + kRingBytes);
 
     BwdPipe pipe;
-    pipe.init(a.packed + kBwdBlobOffset, smem + kSmallLdsBytes, wave, lane);
+    pipe.init(a.packed + kBwdBlobOffset, smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();
@@ -315,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
-                layer_norm_relu_bwd(small + L * kSmallPerLayer, g, j, acc, act, xh, rstd,
+                layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                     ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -18,9 +18,33 @@ using namespace nerf_layout;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 3;                        // LDS ring slots (one 16 KiB stage each)
-constexpr int kSmallLdsBytes = 16384;           // small image (15,616 B) padded
+// The "small" image (bias, gamma, beta per layer, [g][T][r] arrays) in LDS: the four lane groups
+// read the same tile of their own 256-byte row at once, and 256 bytes apart is the same four LDS
+// banks (every read a 2-way conflict: 14 % of the LDS-active cycles of the render kernel).  In LDS
+// the rows are therefore 272 bytes apart (one extra 16-byte column: four banks further per lane
+// group); the global image keeps the dense layout.  LDS map of a workgroup: weight ring first (its
+// LDS-DMA targets then stay below 48 KiB), the small image behind it.
+constexpr int kSmallGStride = 68;               // floats between the lane groups' rows in LDS
+constexpr int kSmallArrayLds = 4 * kSmallGStride;
+constexpr int kSmallPerLayerLds = 3 * kSmallArrayLds;
+constexpr int kSmallLdsFloats = 5 * kSmallPerLayerLds + kOutPad;
+constexpr int kSmallLdsBytes = 16640;           // >= 4 * kSmallLdsFloats, multiple of 128
+static_assert(kSmallLdsBytes >= 4 * kSmallLdsFloats, "small image does not fit");
+constexpr int kRingBytes = kRing * kStageBytes;
 constexpr int kWavesPerWg = 4;
 constexpr int kSamplesPerWave = 16;
+
+// index of element i of the packed (dense) small image in its padded LDS copy
+__host__ __device__ inline int small_lds_index(int i) {
+    if (i >= 5 * kSmallPerLayer) return 5 * kSmallPerLayerLds + (i - 5 * kSmallPerLayer);
+    const int L = i / kSmallPerLayer, rem = i % kSmallPerLayer;
+    const int which = rem / kHidden, q = rem % kHidden;
+    return L * kSmallPerLayerLds + which * kSmallArrayLds + (q / 64) * kSmallGStride + (q % 64);
+}
+// global -> LDS copy by the whole workgroup (256 threads)
+__device__ __forceinline__ void stage_small_image(const float* small_g, float* small_l) {
+    for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[small_lds_index(i)] = small_g[i];
+}
 
 // ---------------------------------------------------------------------------------------------
 // saved-for-backward workspace (training forward writes it, backward reads/extends it)

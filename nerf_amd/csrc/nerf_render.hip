@@ -15,14 +15,14 @@ using namespace nerf_device;
 
 namespace {
 
-constexpr int kLdsBytes = kSmallLdsBytes + kRing * kStageBytes;   // 64 KiB -> 2 workgroups / CU
+constexpr int kLdsBytes = kRingBytes + kSmallLdsBytes;   // 64.25 KiB -> 2 workgroups / CU
 // Split-precision kernel: per-lane state that only the front end and the compositing need (ray,
 // running transmittance / RGB / segmentation sums, interval length) is parked in LDS while the MLP
 // runs, instead of being spilled to scratch (= HBM writes) by the register allocator.
 constexpr int kStashFloatsPerLane = 8;
 constexpr int kStashBytes = kWavesPerWg * 64 * kStashFloatsPerLane * 4;   // 8 KiB
 constexpr int kRayStashBytes = kWavesPerWg * 8 * 4;
-constexpr int kLdsBytesHalf = kLdsBytes + kStashBytes + kRayStashBytes;   // 72.1 KiB -> still 2 / CU
+constexpr int kLdsBytesHalf = kLdsBytes + kStashBytes + kRayStashBytes;   // 72.4 KiB -> still 2 / CU
 
 struct KernelArgs {
     NerfHipRenderArgs a;
@@ -161,14 +161,14 @@ __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&r
     LazyNorm n;
     n.rstd = rstd;
     n.shift = -mean * rstd;
-    n.gam = (const f32x4*)(small_l + kHidden) + g * 16;
-    n.bet = (const f32x4*)(small_l + 2 * kHidden) + g * 16;
+    n.gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
+    n.bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     n.save_row = save_row;
     return n;
 }
 
 __device__ __forceinline__ void load_bias16(const float* small_l, int g, f32x4 (&acc)[16]) {
-    const f32x4* b = (const f32x4*)small_l + g * 16;
+    const f32x4* b = (const f32x4*)(small_l + g * kSmallGStride);
 #pragma unroll
     for (int T = 0; T < 16; ++T) acc[T] = b[T];
 }
@@ -542,14 +542,12 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
     // small image -> LDS (once per workgroup)
     {
-        const float* small_g = a.packed + (kHalf ? kHSmallOffset : kBlobFloats);
-        float* small_l = (float*)smem;
-        for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[i] = small_g[i];
+        stage_small_image(a.packed + (kHalf ? kHSmallOffset : kBlobFloats), (float*)(smem + kRingBytes));
     }
-    const float* small = (const float*)smem;
+    const float* small = (const float*)(smem + kRingBytes);
 
     FwdPipe pipe;
-    pipe.init(a.packed + (kHalf ? kHBlobOffset : 0), smem + kSmallLdsBytes, wave, lane);
+    pipe.init(a.packed + (kHalf ? kHBlobOffset : 0), smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
@@ -640,17 +638,17 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 norm = finish_moments<false, HMoments>(mom, Y, small, g, nullptr, nullptr, eps);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
-                    const float* small_a = small + L * kSmallPerLayer;
+                    const float* small_a = small + L * kSmallPerLayerLds;
                     load_bias16(small_a, g, X);
                     layer_fused_h<8, true>(pipe, Y, X, norm, mom);
                     norm = finish_moments<false, HMoments>(mom, X, small_a, g, nullptr, nullptr, eps);
-                    const float* small_b = small_a + kSmallPerLayer;
+                    const float* small_b = small_a + kSmallPerLayerLds;
                     load_bias16(small_b, g, Y);
                     layer_fused_h<8, true>(pipe, X, Y, norm, mom);
                     norm = finish_moments<false, HMoments>(mom, Y, small_b, g, nullptr, nullptr, eps);
                 }
                 {
-                    const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
+                    const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
 #pragma unroll
                     for (int T = 0; T < 4; ++T) out[T] = b[T];
                 }
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
             for (int L = 1; L <= 4; ++L) {
-                const float* small_l = small + L * kSmallPerLayer;
+                const float* small_l = small + L * kSmallPerLayerLds;
                 load_bias16(small_l, g, Y);
                 layer_fused<kStagesHidden, true, kTrain>(pipe, X, Y, norm, mom);
                 norm = finish_moments<kTrain, Moments>(mom, X, small_l, g, xrow + ka.save.xhat[L],
@@ -679,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----
             {
-                const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayer) + g * 4;
+                const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = b[T];
             }
@@ -962,7 +960,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, true>, kLdsBytesHalf, device,
                                          &done_half);
     if (rc) return rc;
-    int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64 KiB LDS, <= 256 VGPRs)
+    int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64.25 KiB LDS, <= 256 VGPRs)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
