@@ -5,17 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = NeRF.render_image of one full frame per GPU (rays generated in-kernel from the pose,
+One step = NeRF.render_image of the 800x800x128 frame (rays generated in-kernel from the pose,
 deterministic fenceposts, RGB + 50-class segmentation composited): the whole hot path, inputs
-(pose, packed parameters) resident in HBM.  Frames are independent, so ranks shard a batch of
-N poses one frame each with no data-path collective ("weak" scaling; ``--scaling strong`` splits
-ONE frame into row blocks instead).  Rank 0 prints one JSON line.
+(pose, packed parameters) resident in HBM.  Rays are independent, so N GPUs shard the rows of
+ONE frame, 800 / N rows each, with no data-path collective (BASELINE.json config 4, "strong"
+scaling: the default for N > 1; at N = 1 that is the whole frame).  ``--scaling weak`` renders one
+whole frame per GPU instead; for N > 1 the line carries that measurement too (`weak_scaling`),
+taken in the same run.  Rank 0 prints one JSON line.
 
-Two arithmetics of the same kernel (NerfHipRenderArgs.precision), both held to
-the same parity tests: "f16x3" (default here: every fp32 product as three f16 MFMAs with fp32
-accumulation, v_mfma_f32_16x16x32_f16) and "fp32" (exact-fp32 v_mfma_f32_16x16x4_f32).  The
-headline `value` is the selected precision's; at N=1 the other one is measured in the same run and
-reported beside it (`other_precision`).
+The headline (`value`, `dtype`, `roofline`) is the reference's arithmetic: "fp32", exact-fp32 MFMA
+(v_mfma_f32_16x16x4_f32; the reference computes in torch fp32, nerf/model.py:525-542).  The second
+arithmetic of the same kernel (NerfHipRenderArgs.precision) — "f16x3", every
+fp32 product as three f16 MFMAs with fp32 accumulation, held to the same parity tests — is measured
+at N = 1 in the same run with the same step and warm-up counts and reported beside it
+(`other_precision`); ``--precision f16x3`` swaps the two.
 
 roofline: the render kernel is MFMA-bound; achieved = evaluated samples per launch x 601,088
 ALGORITHMIC FLOP / average kernel duration measured with HIP events on the launch stream; peak =
@@ -64,6 +67,18 @@ def look_at(camera_o):
     return cam, NeRF.get_rotation_matrix(eye, up)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(rows=32):
     """Oracle render of `rows` image rows of the bench frame on the host cores."""
     from oracle import nerf_oracle as O
@@ -83,7 +98,7 @@ def cpu_baseline(rows=32):
             O.render_rays(params, cfg, a, b, SAMPLES)
         dt = time.perf_counter() - t0
     return {"value": rows * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "cores": threads,
-            "kind": "port",
+            "kind": "port", "cpu": cpu_model(), "host_cpus": os.cpu_count(),
             "sample": f"{rows} rows x {IMAGE} px of the same 800x800x128 frame, chunks of 1024 rays, "
                       f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
 
@@ -129,7 +144,8 @@ def profiled_traffic(precision):
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
-        if ("f16x3" in os.path.basename(path)) != (precision == "f16x3"):
+        name = os.path.basename(path)
+        if ("f16x3" in name) != (precision == "f16x3") or any(k in name for k in ("train", "bwd", "wgrad")):
             continue
         try:
             with open(path) as f:
@@ -165,14 +181,22 @@ def roofline(precision, rays, kernel_ms, launches, with_traffic):
     }
 
 
+def shard_rows(rank, world):
+    """Row block of rank `rank` when `world` GPUs split one frame (blocks differ by <= 1 row)."""
+    base, extra = divmod(IMAGE, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): the GPUs split the rows of one frame; weak: one frame per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "f16x3"))
+    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "fp32"))
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,32 +222,33 @@ def main():
     model = NeRF(focal_length=FOCAL).to(dev)         # default init, seed 0, on every rank
     model.precision = args.precision
 
-    # a batch of `world` poses on a circle of the same radius; rank r renders frame r (weak) or
-    # its row block of frame 0 (strong)
     import math
-    if args.scaling == "weak":
-        ang = 2.0 * math.pi * rank / max(world, 1)
-        r_xy = math.hypot(CAMERA[0], CAMERA[1])
-        pose = (r_xy * math.sin(ang), -r_xy * math.cos(ang), CAMERA[2])
-        rows = (0, IMAGE)
-    else:
-        pose = CAMERA
-        per = IMAGE // world
-        rows = (rank * per, IMAGE if rank == world - 1 else (rank + 1) * per)
-    cam_o, cam_r = look_at(pose)
-    cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
 
-    def step():
-        with torch.no_grad():
-            return model.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES,
-                                      row_begin=rows[0], row_end=rows[1])
+    def workload(scaling):
+        """(pose, row block) of this rank: its row block of the one frame (strong), or a frame of
+        its own from a pose on the same circle (weak)."""
+        if scaling == "weak":
+            ang = 2.0 * math.pi * rank / max(world, 1)
+            r_xy = math.hypot(CAMERA[0], CAMERA[1])
+            return (r_xy * math.sin(ang), -r_xy * math.cos(ang), CAMERA[2]), (0, IMAGE)
+        return CAMERA, shard_rows(rank, world)
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(steps, warmup):
+    def measure(scaling, steps, warmup):
+        """W untimed + K timed steps between barrier + synchronize pairs; MAX over ranks."""
+        pose, rows = workload(scaling)
+        cam_o, cam_r = look_at(pose)
+        cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+
+        def step():
+            with torch.no_grad():
+                return model.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES,
+                                          row_begin=rows[0], row_end=rows[1])
+
         for _ in range(warmup):
             step()
         fence()
@@ -237,28 +262,28 @@ def main():
         kernel_ms, launches = _lib.timing_read(reset=True)
         _lib.timing(False)
         assert torch.isfinite(out[0]).all()
-        return dt, kernel_ms, launches
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rays_rank = (rows[1] - rows[0]) * IMAGE
+        total_rays = rays_rank * world if scaling == "weak" else IMAGE * IMAGE
+        return {"elapsed": float(t.item()), "kernel_ms": kernel_ms, "launches": launches,
+                "rays_per_rank": rays_rank, "value": total_rays * SAMPLES * steps / float(t.item())}
 
-    elapsed, kernel_ms, launches = timed(args.steps, args.warmup)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    rays_per_rank = (rows[1] - rows[0]) * IMAGE
-    total_rays = rays_per_rank * world if args.scaling == "weak" else IMAGE * IMAGE
-    value = total_rays * SAMPLES * args.steps / elapsed
+    m = measure(args.scaling, args.steps, args.warmup)
+    weak = None
+    if distributed and args.scaling == "strong":
+        weak = measure("weak", args.steps, args.warmup)
 
     if rank == 0:
         line = {
             "metric": "ray-samples/sec at 800x800x128",
-            "value": value,
+            "value": m["value"],
             "unit": "ray-samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -268,29 +293,34 @@ def main():
                 "workload": "NeRF.render_image 800x800, 128 samples/ray (127 evaluated), RGB + 50-class "
                             "segmentation, rays generated in-kernel, default-init weights seed 0",
                 "precision": args.precision,
-                "rays_per_gpu": rays_per_rank,
+                "rays_per_gpu": m["rays_per_rank"],
                 "frames": world if args.scaling == "weak" else 1,
-                "sharding": "one frame per GPU" if args.scaling == "weak" else "row blocks of one frame",
+                "sharding": ("one frame per GPU" if args.scaling == "weak"
+                             else f"{world} row blocks of one frame" if world > 1 else "one frame, one GPU"),
                 "collectives": "none",
                 "rendezvous_backend": backend,
             },
-            "roofline": roofline(args.precision, rays_per_rank, kernel_ms, launches,
-                                 world == 1 and args.scaling == "weak"),
+            "roofline": roofline(args.precision, m["rays_per_rank"], m["kernel_ms"], m["launches"],
+                                 world == 1),
         }
+        if weak is not None:
+            line["weak_scaling"] = {"value": weak["value"], "unit": "ray-samples/s",
+                                    "ms_per_step": weak["elapsed"] / args.steps * 1e3,
+                                    "steps": args.steps, "frames": world,
+                                    "sharding": "one frame per GPU",
+                                    "kernel_ms": weak["kernel_ms"]}
         if world == 1 and not args.no_cpu_baseline:
-            # the other arithmetic of the same kernel, same frame, same run
+            # the other arithmetic of the same kernel: same frame, same run, same step counts
             other = "fp32" if args.precision == "f16x3" else "f16x3"
             model.precision = other
-            o_steps = max(3, args.steps // 4)
-            o_elapsed, o_kernel_ms, o_launches = timed(o_steps, 1)
+            o = measure(args.scaling, args.steps, args.warmup)
             model.precision = args.precision
             line["other_precision"] = {
                 "precision": other, "dtype": PRECISIONS[other]["dtype"],
-                "value": rays_per_rank * SAMPLES * o_steps / o_elapsed, "unit": "ray-samples/s",
-                "steps": o_steps, "ms_per_step": o_elapsed / o_steps * 1e3,
-                "roofline": roofline(other, rays_per_rank, o_kernel_ms, o_launches, True),
+                "value": o["value"], "unit": "ray-samples/s",
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": o["elapsed"] / args.steps * 1e3,
+                "roofline": roofline(other, o["rays_per_rank"], o["kernel_ms"], o["launches"], True),
             }
-        if world == 1 and not args.no_cpu_baseline:
             line["train_step"] = train_step_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 2
+#define NERF_HIP_ABI_VERSION 3
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -48,6 +48,12 @@ int nerf_hip_version(void);
 
 /* Message for the most recent failing call on this thread ("" if none). */
 const char* nerf_hip_last_error(void);
+
+/* Experiment macros (-DNERF_ABL_* / -DNERF_EXP_* / ...) this library was compiled with, space
+ * separated; "" for the product build.  Most of them produce WRONG results on purpose (timing
+ * ablations), so the Python loader refuses a non-empty answer unless the library was selected
+ * explicitly with NERF_HIP_LIB.  No reference counterpart (build hygiene). */
+const char* nerf_hip_build_flags(void);
 
 /* Size in bytes of the packed parameter image consumed by the render kernels. */
 size_t nerf_hip_packed_bytes(void);
@@ -87,7 +93,8 @@ typedef struct NerfHipRenderArgs {
     float density_noise_std;
     int32_t rng_mode;           /* bit0: draw u in-kernel (Philox) when u==NULL;
                                    bit1: draw noise in-kernel when noise==NULL            */
-    uint64_t rng_seed, rng_offset;
+    uint64_t rng_seed, rng_offset;  /* Philox key = seed ^ offset: a distinct offset per launch (and
+                                   per data-parallel rank) gives independent draws            */
     /* --- network */
     float base_radius_sq;       /* (1/(sqrt(3)*focal))^2 with the CONSTRUCTOR focal (:546) */
     const float* packed;        /* image written by nerf_hip_pack_weights                  */
@@ -95,7 +102,10 @@ typedef struct NerfHipRenderArgs {
     float* rgb;                 /* [n_rays,3]  sum_s w_s * sigmoid(color_s)   (model.py:660)*/
     float* seg;                 /* [n_rays,50] log-probabilities (model.py:661-663) or NULL*/
     /* optional per-sample outputs of NeRF.forward (model.py:553-594), any may be NULL      */
-    float* out_mean;            /* [n_rays,S-1,3]                                          */
+    float* out_mean;            /* [n_rays,S-1,3]  Gaussian means (model.py:587)           */
+    float* out_cov;             /* [n_rays,S-1,3]  diagonal covariances (debug / parity)   */
+    float* out_t;               /* [n_rays,S] the fenceposts used (sample_along_rays,
+                                   model.py:369-435; with rng_mode bit0: the in-kernel draws) */
     float* out_raw;             /* [n_rays,S-1,54] density | color | segmentation logits   */
     float* out_weights;         /* [n_rays,S-1] compositing weights (model.py:438-469)     */
     /* training: non-NULL makes the forward also save what the backward needs (activations,

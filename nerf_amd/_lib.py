@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (kernel experiments: scripts/ablate.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -32,7 +32,7 @@ class RenderArgs(ctypes.Structure):
         ("base_radius_sq", ctypes.c_float),
         ("packed", _f32p),
         ("rgb", _f32p), ("seg", _f32p),
-        ("out_mean", _f32p), ("out_raw", _f32p), ("out_weights", _f32p),
+        ("out_mean", _f32p), ("out_cov", _f32p), ("out_t", _f32p), ("out_raw", _f32p), ("out_weights", _f32p),
         ("train_workspace", _f32p),
         ("precision", ctypes.c_int32),
     ]
@@ -99,15 +99,27 @@ def lib():
                                             ctypes.POINTER(ctypes.c_int64)]
     if handle.nerf_hip_version() != ABI_VERSION:
         raise RuntimeError(f"libnerf_hip.so ABI {handle.nerf_hip_version()} != expected {ABI_VERSION}")
+    handle.nerf_hip_build_flags.restype = ctypes.c_char_p
+    flags = handle.nerf_hip_build_flags().decode().split()
+    if flags and not os.environ.get("NERF_HIP_LIB"):
+        raise RuntimeError(
+            f"{LIB_PATH} was compiled with experiment macros {flags} (timing ablations: wrong results "
+            "on purpose); rebuild the product library, or select an experimental build explicitly "
+            "with NERF_HIP_LIB=<path>")
     _lib = handle
     return _lib
 
 
-EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_packed_bytes",
+EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "nerf_hip_packed_bytes",
            "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
            "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
            "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_timing",
            "nerf_hip_timing_read")
+
+
+def build_flags():
+    """Experiment macros of the loaded library ([] for the product build)."""
+    return lib().nerf_hip_build_flags().decode().split()
 
 
 def check(rc, what):

@@ -22,10 +22,7 @@ class RenderRaysFunction(torch.autograd.Function):
         n_rays, device = rays_o.shape[0], rays_o.device
         ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
         workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
-        rng_state = None
-        if rng_mode:
-            rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, model._philox_calls)
-            model._philox_calls += 1
+        rng_state = model._next_philox_state() if rng_mode else None
         rgb, seg, _, _, weights = model._launch(n_rays, num_samples, device, rays_o=rays_o,
                                                 rays_d=rays_d, u=u, noise=noise,
                                                 density_noise_std=density_noise_std, rng_mode=rng_mode,
@@ -33,6 +30,9 @@ class RenderRaysFunction(torch.autograd.Function):
                                                 want_weights=want_weights, train_workspace=workspace)
         if weights is None:
             weights = rgb.new_empty(0)
+        if getattr(model, "keep_workspace", False):      # debugging / stage-parity tests only
+            model.last_workspace = workspace
+        ctx.set_materialize_grads(False)                 # an unused output arrives as None, not zeros
         ctx.model = model
         ctx.call = (rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode, rng_state,
                     t_values)
@@ -53,8 +53,9 @@ class RenderRaysFunction(torch.autograd.Function):
         if d_rgb is None:
             d_rgb = torch.zeros_like(rgb)
         d_rgb = d_rgb.contiguous()
-        use_seg = d_seg is not None and bool((d_seg != 0).any())
-        d_seg = d_seg.contiguous() if use_seg else None
+        # d_seg is None when the segmentation output did not reach the loss (no device sync to find
+        # out): the kernels then skip the 50-class branch of the compositing backward
+        d_seg = d_seg.contiguous() if d_seg is not None else None
 
         args = _lib.BackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, u=u,

@@ -850,13 +850,18 @@ size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
 int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: null args");
     const NerfHipRenderArgs& a = args->fwd;
-    if (args->grad == nullptr || args->scratch == nullptr || args->d_rgb == nullptr)
-        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad / scratch / d_rgb is null");
+    if (args->grad == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad is null");
+    if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
+        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)kGradElements * sizeof(float),
+                                                     (hipStream_t)stream), "render_backward memset");
+    if (args->scratch == nullptr || args->d_rgb == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: scratch / d_rgb is null");
     if (a.train_workspace == nullptr || a.packed == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: forward was not a training forward");
     if (args->d_seg != nullptr && a.seg == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: d_seg given but forward seg is null");
-    if (a.n_rays <= 0 || a.num_samples < 2 || a.num_samples > 4096)
+    if (a.n_rays < 0 || a.num_samples < 2 || a.num_samples > 4096)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: n_rays / num_samples out of range");
     hipStream_t st = (hipStream_t)stream;
 

@@ -109,6 +109,59 @@ struct Timing {
     }
 };
 
+// Experiment macros compiled into this build, space separated ("" for the product build).  Most of
+// them make the kernels compute WRONG results on purpose (timing ablations: scripts/ablate.py);
+// the loader (nerf_amd/_lib.py) refuses such a library unless it was asked for by path.
+inline const char* build_flags() {
+    return ""
+#ifdef NERF_ABL_ENCODE
+           "NERF_ABL_ENCODE "
+#endif
+#ifdef NERF_ABL_COMP
+           "NERF_ABL_COMP "
+#endif
+#ifdef NERF_ABL_LN
+           "NERF_ABL_LN "
+#endif
+#ifdef NERF_ABL_SPLIT
+           "NERF_ABL_SPLIT "
+#endif
+#ifdef NERF_EXP_NOWAIT
+           "NERF_EXP_NOWAIT "
+#endif
+#ifdef NERF_EXP_NOBARRIER
+           "NERF_EXP_NOBARRIER "
+#endif
+#ifdef NERF_EXP_NODMA
+           "NERF_EXP_NODMA "
+#endif
+#ifdef NERF_EXP_NOLDS
+           "NERF_EXP_NOLDS "
+#endif
+#ifdef NERF_EXP_PACKNORM
+           "NERF_EXP_PACKNORM "
+#endif
+#ifdef NERF_EXP_NOPACKMOM
+           "NERF_EXP_NOPACKMOM "
+#endif
+#ifdef NERF_EXP_TRAIN_PLAINWAIT
+           "NERF_EXP_TRAIN_PLAINWAIT "
+#endif
+#ifdef NERF_EXP_WGRAD_NODMA
+           "NERF_EXP_WGRAD_NODMA "
+#endif
+#ifdef NERF_EXP_WGRAD_HID_ONLY
+           "NERF_EXP_WGRAD_HID_ONLY "
+#endif
+#ifdef NERF_WGRAD_FP32
+           "NERF_WGRAD_FP32 "
+#endif
+#ifdef NERF_STAGGER
+           "NERF_STAGGER "
+#endif
+        ;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes
 // are per device, and a process may drive more than one.
 inline int ensure_dynamic_lds(const void* fn, int bytes, int device, unsigned* done_mask) {
@@ -123,9 +176,12 @@ inline int ensure_dynamic_lds(const void* fn, int bytes, int device, unsigned* d
 
 }  // namespace nerf_common
 
-// Philox4x32-10 keyed by (seed), counter = (ray id lo, ray id hi, sample block + offset, stream).
-// Used only when the caller asks the kernel to draw u / noise itself (rng_mode); the parity path
-// takes the draws as inputs.
+// Philox4x32-10.  Key = seed XOR offset, counter = (ray id lo, ray id hi, sample block, stream):
+// the per-launch `offset` (call count, with the data-parallel rank in its high bits) selects an
+// independent KEY, so the draws of successive launches and of different ranks share no counter
+// block (with the offset added to the block index, launch k + 1 would replay launch k's blocks
+// shifted by one).  Used only when the caller asks the kernel to draw u / noise itself (rng_mode);
+// the parity path takes the draws as inputs.
 namespace nerf_rng {
 
 __device__ __forceinline__ void round_(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -143,9 +199,9 @@ __device__ __forceinline__ void philox(uint64_t seed, uint64_t offset, uint64_t 
                                        uint32_t stream, uint32_t (&c)[4]) {
     c[0] = (uint32_t)ray;
     c[1] = (uint32_t)(ray >> 32);
-    c[2] = block + (uint32_t)offset;
-    c[3] = stream ^ (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    c[2] = block;
+    c[3] = stream;
+    uint32_t k0 = (uint32_t)seed ^ (uint32_t)offset, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         round_(c, k0, k1);

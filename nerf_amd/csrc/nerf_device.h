@@ -117,6 +117,9 @@ struct WeightPipe {
             // the MFMAs that consume them.  The DMA's own completion is tracked by hand anyway
             // (open_stage: vmcnt(4) + barrier); DMA ops the compiler does not know about only make
             // its own vmcnt waits more conservative, never too weak (vector memory returns in order).
+            // Asm gets none of the compiler's hazard wait states: the s_nop covers "SGPR written by
+            // a VALU (v_readlane of a spilled SGPR, v_readfirstlane) -> read by VMEM" (5) and
+            // "m0 written -> LDS-DMA" (1); scripts/isa_hazards.py checks R2 / R3 on the emitted code.
             const uint32_t dst = (uint32_t)(uintptr_t)(ring + issue_slot * kStageBytes + wave * 4096);
             uint32_t m0_saved;
             // scalar base (uniform: image + stage + wave) + one 32-bit lane offset
@@ -128,7 +131,7 @@ struct WeightPipe {
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %2\n\t"
-                "s_nop 0\n\t"
+                "s_nop 2\n\t"             /* 5 wait states between any earlier VALU-written SGPR and the loads */
                 "global_load_lds_dwordx4 %1, %3\n\t"
                 "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
@@ -150,9 +153,26 @@ struct WeightPipe {
     // slot the next issue() overwrites: write-after-read safe without any timing argument.
     // The caller reads its first operands, THEN calls issue(): the reads' latency hides under the
     // previous stage's trailing MFMAs instead of behind the DMA address arithmetic.
+    // kYounger: vector-memory operations (x_hat stores of the split-precision training forward) that
+    // this wave is KNOWN to have issued after the DMA of the stage being opened, besides the 4 pieces
+    // of the following stage.  vmcnt counts loads, stores and LDS-DMA together and retires them in
+    // issue order (checked on the hardware: scripts/probes/vmcnt_order.hip), so without it the wait
+    // also covers those stores (an HBM write latency per stage, which a 0.4 us split-precision stage
+    // cannot hide); an under-count only makes the wait stricter, an over-count would let the stage be
+    // read before it has landed.
+    template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
 #ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
+        static_assert(kYounger >= 0 && kYounger <= 4, "vmcnt immediate");
+#ifdef NERF_EXP_TRAIN_PLAINWAIT  /* A/B build: every hand-over waits vmcnt(4) */
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#else
+        if (kYounger == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (kYounger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if (kYounger == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (kYounger == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
 #endif
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();

@@ -138,7 +138,8 @@ __device__ __forceinline__ void interleave_7() {
 template <bool kTrain, class Mom>
 __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
-                                                   float* save_rstd, float eps = 1e-5f) {
+                                                   float* save_rstd, float eps = 1e-5f,
+                                                   float save_scale = 1.0f) {
     const float mean = group_sum(m.sum()) * (1.0f / 256.0f);
     const float ex2 = group_sum(m.sum_sq()) * (1.0f / 256.0f);
     float var = ex2 - mean * mean;
@@ -157,7 +158,7 @@ __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&r
     const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-    if (kTrain && g == 0) *save_rstd = rstd;
+    if (kTrain && g == 0) *save_rstd = rstd * save_scale;
     LazyNorm n;
     n.rstd = rstd;
     n.shift = -mean * rstd;
@@ -289,7 +290,8 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-precision ("f16x3") layers of the inference path: every fp32 operand is an f16 pair
+// Split-precision ("f16x3") layers of the forward (inference, and the training forward on request):
+// every fp32 operand is an f16 pair
 // (hi, lo) and a product is three v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi, fp32
 // accumulate; the dropped lo.lo term is ~2^-22 relative), 5.3x the fp32-MFMA rate per product.
 // Image and scalings: nerf_layout.h.  A k block m = register tiles 2m, 2m+1 of the input; its
@@ -322,14 +324,21 @@ __device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c
 __device__ __forceinline__ h2 pack_rtz(float a, float b) {
     return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
 }
-// x - (float)pair[kHigh] in one instruction (v_fma_mix_f32 reads the f16 half directly)
+// x - (float)pair[kHigh] in one instruction (v_fma_mix_f32 reads the f16 half directly; the compiler
+// itself only emits v_cvt_f32_f16 + v_sub_f32 for this).
+// Inline asm gets NONE of the wait states hipcc inserts around MFMAs (its hazard recognizer does not
+// look inside asm), so the instruction may only touch registers that a compiler-visible VALU
+// instruction wrote last (scripts/isa_hazards.py, rule R1): the result is tied to `x`'s register
+// ("+v": x itself if it dies here, else a v_mov copy — either way written by a visible VALU after
+// every MFMA that used the register), never a fresh temporary, which the allocator is free to take
+// from the accumulators of MFMAs still in flight.
 template <int kHigh>
 __device__ __forceinline__ float residual(float x, const h2& pair) {
-    float r;
+    float r = x;
     if (kHigh)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
     else
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(x));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
     return r;
 }
 
@@ -380,14 +389,14 @@ constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unrolle
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
 // built (normalise tile by tile, then split) during stage (0, m).
-template <int KB, bool kNormIn>
+template <int KB, bool kNormIn, bool kTrain>
 __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
                                               const LazyNorm& norm, HMoments& mom) {
     constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
     h8 bhi[KB], blo[KB];
     if (kNormIn) {
-        normalize_tile<false, kPackNorm>(in[0], norm, 0);
-        normalize_tile<false, kPackNorm>(in[1], norm, 1);
+        normalize_tile<kTrain, kPackNorm>(in[0], norm, 0);
+        normalize_tile<kTrain, kPackNorm>(in[1], norm, 1);
     }
     split8(in[0], in[1], bhi[0], blo[0]);
     mom.reset();
@@ -415,7 +424,15 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
             __builtin_amdgcn_sched_barrier(0);
             if (U + kSets - 1 < kUnits) {
                 const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
-                if (ip == 0) st = (const h8*)pipe.open_stage();
+                if (ip == 0) {
+                    // training: the x_hat stores of this stage (units 1 and 3, before this hand-over)
+                    // and of the previous one are younger than the DMA of the stage being opened
+                    constexpr bool kStores = kTrain && kNormIn;
+                    const bool mine = kStores && build_next, prev = kStores && s >= 1 && s - 1 < KB - 1;
+                    if (mine && prev) st = (const h8*)pipe.template open_stage<4>();
+                    else if (mine || prev) st = (const h8*)pipe.template open_stage<2>();
+                    else st = (const h8*)pipe.open_stage();
+                }
                 ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
                 al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
                 if (ip == 0) pipe.prefetch_next();
@@ -429,9 +446,9 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
             out[T] = mfma_h(al[set], bhi[m], out[T]);
             // VALU riding in the shadow of this unit's MFMAs
             if (build_next) {
-                if (kNormIn && i == 1) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (kNormIn && i == 1) normalize_tile<kTrain, kPackNorm>(in[ta], norm, ta, ga, be);
                 if (i == 2) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
-                if (kNormIn && i == 3) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (kNormIn && i == 3) normalize_tile<kTrain, kPackNorm>(in[tb], norm, tb, ga, be);
                 if (i == 4) {
                     split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
                     bhi[m + 1] = join8(nh[0], nh[1], nh[2], nh[3]);
@@ -463,12 +480,13 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
 
 // Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
 // block m + 1 is built during the four units of block m.
+template <bool kTrain>
 __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
                                             const LazyNorm& norm) {
     constexpr int kUnits = 8 * kStagesL5;
     h8 bh[2], bl[2];
-    normalize_tile<false, kPackNorm>(in[0], norm, 0);
-    normalize_tile<false, kPackNorm>(in[1], norm, 1);
+    normalize_tile<kTrain, kPackNorm>(in[0], norm, 0);
+    normalize_tile<kTrain, kPackNorm>(in[1], norm, 1);
     split8(in[0], in[1], bh[0], bl[0]);
     h8 ah[kSets], al[kSets];
     f32x4 ga = norm.gam[2], be = norm.bet[2];
@@ -510,9 +528,9 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
             acc[T] = mfma_h(ah[set], bl[pb], acc[T]);
             acc[T] = mfma_h(al[set], bh[pb], acc[T]);
             if (m + 1 < 8) {
-                if (q == 0) normalize_tile<false, kPackNorm>(in[ta], norm, ta, ga, be);
+                if (q == 0) normalize_tile<kTrain, kPackNorm>(in[ta], norm, ta, ga, be);
                 if (q == 1) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
-                if (q == 2) normalize_tile<false, kPackNorm>(in[tb], norm, tb, ga, be);
+                if (q == 2) normalize_tile<kTrain, kPackNorm>(in[tb], norm, tb, ga, be);
                 if (q == 3) {
                     split4(in[tb], nh[2], nh[3], nl[2], nl[3]);
                     bh[pb ^ 1] = join8(nh[0], nh[1], nh[2], nh[3]);
@@ -529,9 +547,12 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool kTrain, bool kHalf>
+// kPerSample: the instantiation that also writes the optional per-sample outputs (NeRF.forward's
+// tensors, compositing weights for the hierarchical resampler, debug outputs); the render-only
+// instantiations carry none of that code or its registers.
+template <bool kTrain, bool kHalf, bool kPerSample = false>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
-    static_assert(!(kTrain && kHalf), "the split-precision path is inference only");
+    static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -579,12 +600,12 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
         racc.reset();
         float* const stash = (float*)(smem + kLdsBytes) + (wave * 64 + lane) * kStashFloatsPerLane;
         float* const ray_stash = (float*)(smem + kLdsBytes + kStashBytes) + wave * 8;
-        if (kHalf && lane == 0) {
+        if (kHalf && !kTrain && lane == 0) {     // (a training item is one chunk: nothing to park)
             *(f32x4*)ray_stash = f32x4{ray.o[0], ray.o[1], ray.o[2], ray.d[0]};
             ray_stash[4] = ray.d[1];
             ray_stash[5] = ray.d[2];
         }
-        if (kHalf) asm volatile("" ::: "memory");    // the reads of the stash below stay below
+        if (kHalf && !kTrain) asm volatile("" ::: "memory");    // the reads of the stash below stay below
 
         const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
         const int c_end = kTrain ? c_begin + 1 : chunks;
@@ -593,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             const bool ok = s < P;
             const int64_t tile = slot * chunks + c;         // chunk index in the workspace
             const int64_t sp = tile * 16 + j;               // padded sample index
-            if (kHalf) {                                    // the wave's ray, back from LDS (broadcast)
+            if (kHalf && !kTrain) {                         // the wave's ray, back from LDS (broadcast)
                 const f32x4 r0 = *(const f32x4*)ray_stash;
                 ray.o[0] = r0.x, ray.o[1] = r0.y, ray.o[2] = r0.z, ray.d[0] = r0.w;
                 ray.d[1] = ray_stash[4], ray.d[2] = ray_stash[5];
@@ -629,33 +650,40 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
                 const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
                                   (float)(1 << (kWScaleLog2 + kXScaleLog2));
-                *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
-                *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
+                // x_hat is scale-free; the saved 1/std is the one of the unscaled activations
+                const float rs = (float)(1 << (kWScaleLog2 + kXScaleLog2));
+                if (!kTrain) {
+                    *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
+                    *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
+                }
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
                 load_bias16(small, g, Y);
-                layer_fused_h<3, false>(pipe, X, Y, norm, mom);
-                norm = finish_moments<false, HMoments>(mom, Y, small, g, nullptr, nullptr, eps);
+                layer_fused_h<3, false, kTrain>(pipe, X, Y, norm, mom);
+                norm = finish_moments<kTrain, HMoments>(mom, Y, small, g, xrow + ka.save.xhat[0],
+                                                        rstd_p + ka.save.rstd[0], eps, rs);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
                     const float* small_a = small + L * kSmallPerLayerLds;
                     load_bias16(small_a, g, X);
-                    layer_fused_h<8, true>(pipe, Y, X, norm, mom);
-                    norm = finish_moments<false, HMoments>(mom, X, small_a, g, nullptr, nullptr, eps);
+                    layer_fused_h<8, true, kTrain>(pipe, Y, X, norm, mom);
+                    norm = finish_moments<kTrain, HMoments>(mom, X, small_a, g, xrow + ka.save.xhat[L],
+                                                            rstd_p + ka.save.rstd[L], eps, rs);
                     const float* small_b = small_a + kSmallPerLayerLds;
                     load_bias16(small_b, g, Y);
-                    layer_fused_h<8, true>(pipe, X, Y, norm, mom);
-                    norm = finish_moments<false, HMoments>(mom, Y, small_b, g, nullptr, nullptr, eps);
+                    layer_fused_h<8, true, kTrain>(pipe, X, Y, norm, mom);
+                    norm = finish_moments<kTrain, HMoments>(mom, Y, small_b, g, xrow + ka.save.xhat[L + 1],
+                                                            rstd_p + ka.save.rstd[L + 1], eps, rs);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
 #pragma unroll
                     for (int T = 0; T < 4; ++T) out[T] = b[T];
                 }
-                layer_out_h(pipe, Y, out, norm);
+                layer_out_h<kTrain>(pipe, Y, out, norm);
 #pragma unroll
-                for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2)));
-                {
+                for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / rs);
+                if (!kTrain) {
                     const f32x4 s0 = *(const f32x4*)stash, s1 = *(const f32x4*)(stash + 4);
                     racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
                     racc.seg_m = s1.x, racc.seg_s = s1.y, dist = s1.z;
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             // ---- compositing (nerf/model.py:438-469, :660-663) ----
             const float w = composite_chunk<false>(a, P, local, s, ok, lane, out, dist, racc, nullptr);
             // optional per-sample outputs (NeRF.forward, nerf/model.py:553-594)
-            if (ray_ok && ok) {
+            if (kPerSample && ray_ok && ok) {
                 const int64_t smp = local * P + s;
                 if (a.out_raw != nullptr) {
 #pragma unroll
@@ -709,16 +737,27 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                         }
                 }
                 if (g == 0) {
-                    if (a.out_mean != nullptr) {
+                    if (a.out_mean != nullptr || a.out_cov != nullptr) {
                         // recomputed (same operations, same bits) rather than kept live across the MLP
                         const Gaussian gm = kHalf ? frustum(ray, fencepost(a, local, s), fencepost(a, local, s + 1),
                                                             a.base_radius_sq)
                                                   : gs;
-                        a.out_mean[smp * 3 + 0] = gm.mean[0];
-                        a.out_mean[smp * 3 + 1] = gm.mean[1];
-                        a.out_mean[smp * 3 + 2] = gm.mean[2];
+                        if (a.out_mean != nullptr) {
+                            a.out_mean[smp * 3 + 0] = gm.mean[0];
+                            a.out_mean[smp * 3 + 1] = gm.mean[1];
+                            a.out_mean[smp * 3 + 2] = gm.mean[2];
+                        }
+                        if (a.out_cov != nullptr) {
+                            a.out_cov[smp * 3 + 0] = gm.cov[0];
+                            a.out_cov[smp * 3 + 1] = gm.cov[1];
+                            a.out_cov[smp * 3 + 2] = gm.cov[2];
+                        }
                     }
                     if (a.out_weights != nullptr) a.out_weights[smp] = w;
+                    if (a.out_t != nullptr) {           // recomputed: same operations, same bits
+                        a.out_t[local * a.num_samples + s] = fencepost(a, local, s);
+                        if (s == P - 1) a.out_t[local * a.num_samples + s + 1] = fencepost(a, local, s + 1);
+                    }
                 }
             }
         }
@@ -889,6 +928,8 @@ int nerf_hip_version(void) { return NERF_HIP_ABI_VERSION; }
 
 const char* nerf_hip_last_error(void) { return nerf_common::last_error(); }
 
+const char* nerf_hip_build_flags(void) { return nerf_common::build_flags(); }
+
 size_t nerf_hip_packed_bytes(void) { return (size_t)kPackedFloats * sizeof(float); }
 
 size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
@@ -937,10 +978,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     const bool train = a.train_workspace != nullptr;
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
-    if (train && a.precision != NERF_HIP_PRECISION_FP32)
-        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: the training forward is fp32 only");
-    if (train && (a.out_raw != nullptr || a.out_mean != nullptr))
-        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean are not produced by the training forward");
+    if (train && (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr || a.out_t != nullptr))
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean / out_cov / out_t are not produced by the training forward");
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave
     ka.groups = train ? ka.save.mp / 16 / kWavesPerWg : (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
 
@@ -950,28 +989,32 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static unsigned done_infer = 0, done_train = 0, done_half = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, false>, kLdsBytes, device,
-                                         &done_infer);
+    const bool half = a.precision == NERF_HIP_PRECISION_F16X3;
+    const bool per_sample = a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr ||
+                            a.out_t != nullptr || a.out_weights != nullptr;
+    typedef void (*Kernel)(const KernelArgs);
+    // [train][half][per_sample]
+    static const Kernel kernels[2][2][2] = {
+        {{nerf_render_fwd_kernel<false, false, false>, nerf_render_fwd_kernel<false, false, true>},
+         {nerf_render_fwd_kernel<false, true, false>, nerf_render_fwd_kernel<false, true, true>}},
+        {{nerf_render_fwd_kernel<true, false, false>, nullptr},
+         {nerf_render_fwd_kernel<true, true, false>, nullptr}}};
+    static unsigned done[2][2][2] = {};
+    // training: compositing is its own kernel, which also writes out_weights
+    const int ps = !train && per_sample;
+    const Kernel kernel = kernels[train][half][ps];
+    const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
+    rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, &done[train][half][ps]);
     if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<true, false>, kLdsBytes, device,
-                                         &done_train);
-    if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_render_fwd_kernel<false, true>, kLdsBytesHalf, device,
-                                         &done_half);
-    if (rc) return rc;
-    int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (64.25 KiB LDS, <= 256 VGPRs)
+    int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, ka);
     if (train) {
-        hipLaunchKernelGGL((nerf_render_fwd_kernel<true, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
-    } else if (a.precision == NERF_HIP_PRECISION_F16X3)
-        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, true>), dim3((unsigned)grid), dim3(256), kLdsBytesHalf, st, ka);
-    else
-        hipLaunchKernelGGL((nerf_render_fwd_kernel<false, false>), dim3((unsigned)grid), dim3(256), kLdsBytes, st, ka);
+    }
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

@@ -103,7 +103,11 @@ class PixelRayDataset(data.Dataset):
         """One epoch of collated batches: a uniform permutation without replacement (what
         ``DataLoader(shuffle=True)`` draws), cut into batches; with ``world_size`` > 1 every rank
         takes its contiguous share of each global batch (same permutation on all ranks when the
-        generators are seeded alike)."""
+        generators are seeded alike).  Shares differ by at most one example (``parallel.shard_items``;
+        the last batch of an epoch may leave a rank with fewer, even zero, examples) and every batch
+        carries ``global_n``, the size of the global batch, so that a data-parallel step can weight
+        its gradient by ``local / global`` (``parallel.FlatGradientAllReduce``)."""
+        from .parallel import shard_items
         dev, total = self.images.device, len(self)
         order = (torch.randperm(total, device=dev, generator=generator) if shuffle
                  else torch.arange(total, device=dev))
@@ -111,7 +115,10 @@ class PixelRayDataset(data.Dataset):
             idx = order[lo:lo + batch_size]
             if drop_last and idx.shape[0] < batch_size:
                 return
+            global_n = int(idx.shape[0])
             if world_size > 1:
-                per = -(-idx.shape[0] // world_size)
-                idx = idx[rank * per:(rank + 1) * per]
-            yield self.gather(idx)
+                begin, end = shard_items(global_n, rank, world_size)
+                idx = idx[begin:end]
+            batch = self.gather(idx)
+            batch["global_n"] = global_n
+            yield batch

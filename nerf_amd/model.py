@@ -124,6 +124,9 @@ class NeRF(nn.Module):
         # precision of the MLP in inference launches (anything that does not record a backward):
         # "fp32" = exact-fp32 MFMA, "f16x3" = split-precision f16 MFMA (include/nerf_hip.h).
         self.precision = "fp32"
+        # arithmetic of the training FORWARD's MLP (launches that record a backward); the data and
+        # weight gradients keep their own arithmetic (fp32 MFMA / bf16 triples).
+        self.train_precision = "fp32"
         self._packed = None
         self._packed_key = None
         self._tables = {}
@@ -185,7 +188,28 @@ class NeRF(nn.Module):
         return self._tables[key]
 
     def _t_scale(self):
-        return float(torch.linalg.norm(self.rays_max.detach().cpu() - self.rays_min.detach().cpu()))
+        """|rays_max - rays_min| (nerf/model.py:435) as a host float.  The two buffers only change
+        at construction, ``load_state_dict`` or ``.to()``, so the value is cached on their
+        (storage, version) and the device -> host copy happens once, not on every launch."""
+        key = (self.rays_min.data_ptr(), self.rays_min._version, self.rays_max.data_ptr(),
+               self.rays_max._version)
+        if getattr(self, "_t_scale_key", None) != key:
+            self._t_scale_value = float(torch.linalg.norm(self.rays_max.detach().cpu()
+                                                          - self.rays_min.detach().cpu()))
+            self._t_scale_key = key
+        return self._t_scale_value
+
+    def _next_philox_state(self):
+        """(seed, offset) of the next in-kernel draw: the offset counts this module's launches and
+        carries the data-parallel rank in its high bits, so neither successive steps nor the ranks
+        of a job share a Philox key (include/nerf_hip.h: key = seed ^ offset)."""
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF,
+                 ((rank & 0xFFFFFF) << 40) | (self._philox_calls & 0xFFFFFFFFFF))
+        self._philox_calls += 1
+        return state
 
     def sample_along_rays(self, rays_o, rays_d, num_samples, states_x=None, states_d=None,
                           randomly_sample=True):
@@ -248,9 +272,11 @@ class NeRF(nn.Module):
         if getattr(self, "_f16x3_checked", None) == key:
             return
         heads = self.prediction_heads
-        w_max = max(float(heads[i].weight.detach().abs().max()) for i in (0, 3, 6, 9, 12, 15))
-        act_max = max(16.0 * float(heads[i].weight.detach().abs().max()) + float(heads[i].bias.detach().abs().max())
-                      for i in (1, 4, 7, 10, 13))
+        with torch.no_grad():                       # one device -> host copy per parameter version
+            w_dev = torch.stack([heads[i].weight.abs().max() for i in (0, 3, 6, 9, 12, 15)]).max()
+            a_dev = torch.stack([16.0 * heads[i].weight.abs().max() + heads[i].bias.abs().max()
+                                 for i in (1, 4, 7, 10, 13)]).max()
+            w_max, act_max = (float(v) for v in torch.stack([w_dev, a_dev]).cpu())
         if w_max * 256.0 >= 65504.0 or act_max * 16.0 >= 65504.0:
             raise ValueError(f"nerf_amd: parameters out of range for precision='f16x3' (max |w| {w_max:.3g}, "
                              f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
@@ -259,7 +285,7 @@ class NeRF(nn.Module):
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
                    cameras=None, ray_begin=0, t_values=None, u=None, noise=None,
                    density_noise_std=0.0, rng_mode=0, rng_state=None, packed=None, rgb=None, seg=None,
-                   mean=None, raw=None, weights=None, train_workspace=None):
+                   mean=None, cov=None, raw=None, weights=None, train_workspace=None, out_t=None):
         """Fill a NerfHipRenderArgs block (include/nerf_hip.h) from tensors."""
         args.rays_o, args.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
         if cameras is not None:
@@ -278,11 +304,13 @@ class NeRF(nn.Module):
         args.base_radius_sq = r_dot ** 2
         args.packed = _lib.ptr(packed)
         args.rgb, args.seg = _lib.ptr(rgb), _lib.ptr(seg)
-        args.out_mean, args.out_raw, args.out_weights = _lib.ptr(mean), _lib.ptr(raw), _lib.ptr(weights)
+        args.out_mean, args.out_cov, args.out_t = _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(out_t)
+        args.out_raw, args.out_weights = _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
-        if self.precision not in _lib.PRECISIONS:
-            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
-        args.precision = 0 if train_workspace is not None else _lib.PRECISIONS[self.precision]
+        which = self.precision if train_workspace is None else self.train_precision
+        if which not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {which!r}")
+        args.precision = _lib.PRECISIONS[which]
         if args.precision == _lib.PRECISIONS["f16x3"]:
             self._check_f16x3_range()
 
@@ -296,7 +324,7 @@ class NeRF(nn.Module):
     def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
                 ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
                 want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None,
-                train_workspace=None, want_weights=False):
+                train_workspace=None, want_weights=False, cov=None, out_t=None):
         lib = _lib.lib()
         packed = self.packed_parameters()
         P = num_samples - 1
@@ -312,14 +340,13 @@ class NeRF(nn.Module):
         elif want_weights:
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         if rng_mode and rng_state is None:
-            rng_state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._philox_calls)
-            self._philox_calls += 1
+            rng_state = self._next_philox_state()
         args = _lib.RenderArgs()
         self._fill_args(args, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
                         cameras=cameras, ray_begin=ray_begin, t_values=t_values, u=u, noise=noise,
                         density_noise_std=density_noise_std, rng_mode=rng_mode, rng_state=rng_state,
-                        packed=packed, rgb=rgb, seg=seg, mean=mean, raw=raw, weights=weights,
-                        train_workspace=train_workspace)
+                        packed=packed, rgb=rgb, seg=seg, mean=mean, cov=cov, raw=raw, weights=weights,
+                        train_workspace=train_workspace, out_t=out_t)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nerf_hip_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
@@ -354,6 +381,34 @@ class NeRF(nn.Module):
             want_seg=False, per_sample=True)
         density, color, seg = raw.split([1, self.color_outputs, self.segmentation_outputs], dim=2)
         return mean, density, color, seg
+
+    def fenceposts_used(self, rays_o, rays_d, num_samples, randomly_sample=False, u=None, rng_state=None):
+        """The fenceposts [N, S] a render of these rays uses, straight from the kernel's front end:
+        deterministic, stratified from given ``u`` [N, S], or — ``self.rng == "philox"`` — from the
+        in-kernel draws of the NEXT launch state (or of ``rng_state``).  Debugging / parity aid."""
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        n_rays = rays_o.shape[0]
+        out = torch.empty(n_rays, num_samples, dtype=torch.float32, device=rays_o.device)
+        mode = 1 if (randomly_sample and u is None) else 0
+        self._launch(n_rays, num_samples, rays_o.device, rays_o=rays_o.detach().contiguous(),
+                     rays_d=rays_d.detach().contiguous(), u=None if u is None else u.detach().contiguous(),
+                     rng_mode=mode, rng_state=rng_state, want_seg=False, out_t=out)
+        return out
+
+    def integrated_pe(self, rays_o, rays_d, samples):
+        """(means, covs, h) of the intervals of ``samples`` [N, S]  (nerf/model.py:544-551): the
+        Gaussians come from the kernel's front end (the values the MLP is fed from), the 96
+        features from the torch helper above on the same device — a debugging aid, like the
+        reference's method; the renderer never materialises ``h``."""
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        _require_device(samples, "samples")
+        n_rays, num_samples = samples.shape[0], samples.shape[-1]
+        cov = torch.empty(n_rays, num_samples - 1, 3, dtype=torch.float32, device=rays_o.device)
+        _, _, mean, _, _ = self._launch(
+            n_rays, num_samples, rays_o.device, rays_o=rays_o.detach().contiguous(),
+            rays_d=rays_d.detach().contiguous(), t_values=samples.detach().contiguous(),
+            want_seg=False, per_sample=True, cov=cov)
+        return mean, cov, integrated_pos_enc((mean, cov), -4, self.encoding_size // 2 - 4)
 
     def render_rays(self, rays_o, rays_d, num_samples, states_x=None, states_d=None,
                     randomly_sample=False, density_noise_std=0.0, u=None, noise=None):

@@ -54,19 +54,46 @@ def _gather_rows(block, image_h, world_size):
 
 
 class FlatGradientAllReduce:
-    """Average the gradients of ``params`` over the process group with ONE collective.
+    """Weighted sum of the gradients of ``params`` over the process group with ONE collective.
 
-    The gradients are packed into one flat fp32 buffer (1.2 MB for the NeRF MLP), all-reduced
-    (sum), divided by the world size and unpacked in place."""
+    ``weight`` is this rank's share of the global batch (local rays / global rays; 1 / world for
+    equal shards): with a loss that is the MEAN over the rank's rays, sum_r weight_r * grad_r is
+    the gradient of the mean over the global batch, also when the shards are uneven or empty.
+
+    Fast path: the HIP backward already emits the flat 304,438-element vector in ``params`` order
+    with every ``p.grad`` a view of it (``model.last_flat_grad``; true whenever the gradients were
+    ``None`` before ``backward()``, i.e. ``zero_grad(set_to_none=True)``).  Pass it as ``flat`` and
+    the collective runs in place on it: one scale + one all-reduce, no copies.  Otherwise the
+    gradients are packed into a flat buffer and unpacked again (any module, CPU tests)."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         self._flat = None
+        self.in_place_calls = 0
 
-    def __call__(self):
+    def _aliases(self, flat):
+        """Every gradient is the view of ``flat`` at its offset (host-side pointer checks only)."""
+        if flat is None or flat.numel() != self.numel or not flat.is_contiguous():
+            return False
+        off, base, item = 0, flat.data_ptr(), flat.element_size()
+        for p in self.params:
+            g = p.grad
+            if g is None or g.dtype != flat.dtype or not g.is_contiguous() or g.data_ptr() != base + off * item:
+                return False
+            off += p.numel()
+        return True
+
+    def __call__(self, flat=None, weight=None):
         world = dist.get_world_size(self.group)
+        weight = 1.0 / world if weight is None else float(weight)
+        if self._aliases(flat):
+            self.in_place_calls += 1
+            if world > 1:
+                flat.mul_(weight)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return flat
         ref = self.params[0]
         if self._flat is None or self._flat.device != ref.device:
             self._flat = torch.empty(self.numel, dtype=torch.float32, device=ref.device)
@@ -79,8 +106,8 @@ class FlatGradientAllReduce:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         if world > 1:
+            flat.mul_(weight)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(world)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -101,19 +128,19 @@ def broadcast_parameters(module, src=0, group=None):
 class DataParallelTrainer:
     """Data-parallel training step: local forward/backward on this rank's rays, one flat
     all-reduce, redundant optimiser step.  ``loss_fn(model, batch) -> scalar`` must be the MEAN
-    over the rank's rays so that the average over ranks equals the mean over the global batch
-    (equal shard sizes)."""
+    over the rank's rays; ``weight`` (local rays / global rays) makes the reduced gradient the one
+    of the mean over the global batch for uneven shards too (default: equal shards)."""
 
     def __init__(self, model, optimizer, loss_fn, group=None):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.reduce = FlatGradientAllReduce(model.parameters(), group)
         self.distributed = dist.is_available() and dist.is_initialized()
 
-    def step(self, batch):
-        self.optimizer.zero_grad(set_to_none=False)
+    def step(self, batch, weight=None):
+        self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
         loss = self.loss_fn(self.model, batch)
         loss.backward()
         if self.distributed:
-            self.reduce()
+            self.reduce(getattr(self.model, "last_flat_grad", None), weight)
         self.optimizer.step()
         return loss.detach()

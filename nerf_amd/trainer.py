@@ -84,6 +84,10 @@ class Trainer:
             model = NeRF(focal_length=focal_length).to(device)
         self.model = model
         self.model.rng = rng
+        # draws: with rng="torch" the stratified / noise draws come from torch's generator, so give
+        # every rank its own stream (seed + rank); the in-kernel Philox path folds the rank into its
+        # key by itself (NeRF._next_philox_state).  The example order (self.sampler) stays common.
+        self.draws = torch.Generator(device=device).manual_seed(seed + 7919 * (self.rank + 1))
         if self.distributed:
             parallel.broadcast_parameters(self.model)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate)
@@ -105,14 +109,23 @@ class Trainer:
                 json.dump(params, f, indent=4)
 
     def train_step(self, batch):
+        n = batch["rays_o"].shape[0]
+        u = noise = None
+        if self.model.rng == "torch" and self.distributed:
+            # same draws a single process would make (rand, then randn), from this rank's generator
+            u = torch.rand(n, self.num_samples, dtype=torch.float32, device=batch["rays_o"].device,
+                           generator=self.draws)
+            noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32,
+                                device=batch["rays_o"].device, generator=self.draws)
         pixels, _ = self.model.render_rays(batch["rays_o"], batch["rays_d"], self.num_samples,
                                            randomly_sample=True,
-                                           density_noise_std=self.density_noise_std)
-        self.optimizer.zero_grad(set_to_none=False)
-        loss = ((pixels - batch["pixels"].unsqueeze(1)) ** 2).mean()
+                                           density_noise_std=self.density_noise_std, u=u, noise=noise)
+        self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
+        # sum / count instead of mean(): an empty shard (tail of an epoch) gives 0, not NaN
+        loss = ((pixels - batch["pixels"].unsqueeze(1)) ** 2).sum() / max(3 * n, 1)
         loss.backward()
         if self.distributed:
-            self.reduce()
+            self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
         self.optimizer.step()
         return loss.detach()
 

@@ -1,0 +1,84 @@
+"""Python mirror of the training workspace layout (nerf_amd/csrc/nerf_device.h: TrainLayout) — what
+the training forward saves for the backward.  Debugging and stage-parity aid: tests read the encoded
+inputs ``h``, the normalised activations ``x_hat`` and the LayerNorm statistics of every layer
+straight from the buffer the kernels wrote (``model.keep_workspace = True`` keeps it after a
+forward).  The product never reads the workspace from Python.
+"""
+import torch
+
+HIDDEN, ENC_IN, OUT_PAD = 256, 96, 64
+SAMPLES_PER_WAVE = 16
+
+
+def chunks_of(num_samples):
+    return (num_samples - 1 + SAMPLES_PER_WAVE - 1) // SAMPLES_PER_WAVE
+
+
+def train_layout(n_rays, num_samples):
+    """Offsets (in floats) of the saved tensors, like ``make_train_layout``: ``mp`` padded samples
+    = ceil4(n_rays) * chunks * 16; row tensors are [mp, features]."""
+    chunks = chunks_of(num_samples)
+    mp = (n_rays + 3) // 4 * 4 * chunks * 16
+    lay, off = {"mp": mp, "chunks": chunks}, 0
+    lay["h"] = off
+    off += mp * ENC_IN
+    lay["dy"] = []
+    for _ in range(5):
+        lay["dy"].append(off)
+        off += mp * HIDDEN
+    lay["dy5"] = off
+    off += mp * OUT_PAD
+    lay["xhat"] = []
+    for _ in range(5):
+        lay["xhat"].append(off)
+        off += mp * HIDDEN
+    lay["rstd"] = []
+    for _ in range(5):
+        lay["rstd"].append(off)
+        off += mp
+    lay["out"] = off
+    off += mp * OUT_PAD
+    lay["comp"] = off
+    off += mp * 4
+    lay["total"] = off
+    return lay
+
+
+def layer0_feature_order():
+    """Column c = 16 t + 4 g + r of the saved ``h`` rows holds the reference's feature
+    ``layer0_source_feature(t, g, r)`` (nerf_layout.h): [sin: scale-major x coord-minor | shifted]."""
+    order = []
+    for c in range(ENC_IN):
+        t, g, r = c // 16, (c % 16) // 4, c % 4
+        q = 4 * t + r
+        part, p = q // 12, q % 12
+        order.append(part * 48 + 3 * (4 * g + p // 3) + p % 3)
+    return torch.tensor(order, dtype=torch.int64)
+
+
+def _rows(workspace, lay, offset, width, n_rays, num_samples):
+    """[mp, width] rows -> [n_rays, S-1, width] (padded ray slots and samples dropped)."""
+    chunks, mp = lay["chunks"], lay["mp"]
+    rows = workspace[offset:offset + mp * width].view(mp // (chunks * 16), chunks * 16, width)
+    return rows[:n_rays, :num_samples - 1]
+
+
+def saved_h(workspace, n_rays, num_samples):
+    """Encoded inputs [n_rays, S-1, 96] in the REFERENCE's feature order."""
+    lay = train_layout(n_rays, num_samples)
+    h = _rows(workspace, lay, lay["h"], ENC_IN, n_rays, num_samples)
+    out = torch.empty_like(h)
+    out[..., layer0_feature_order().to(h.device)] = h
+    return out
+
+
+def saved_xhat(workspace, layer, n_rays, num_samples):
+    """Normalised pre-affine activations of hidden layer ``layer`` (0..4): [n_rays, S-1, 256]."""
+    lay = train_layout(n_rays, num_samples)
+    return _rows(workspace, lay, lay["xhat"][layer], HIDDEN, n_rays, num_samples)
+
+
+def saved_rstd(workspace, layer, n_rays, num_samples):
+    """1 / sqrt(var + eps) of hidden layer ``layer``: [n_rays, S-1]."""
+    lay = train_layout(n_rays, num_samples)
+    return _rows(workspace, lay, lay["rstd"][layer], 1, n_rays, num_samples)[..., 0]

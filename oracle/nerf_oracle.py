@@ -187,6 +187,27 @@ def mlp(params, h):
     return x
 
 
+def mlp_stages(params, h):
+    """The same network as ``mlp`` with the LayerNorm internals exposed: per hidden layer the
+    normalised pre-affine activations x_hat = (x - mean) / sqrt(var + 1e-5) and 1 / sqrt(var + 1e-5)
+    (biased variance, torch.nn.LayerNorm, nerf/model.py:525-542).  For stage-by-stage parity of the
+    training forward's saved tensors."""
+    x = F.linear(h, params["prediction_heads.0.weight"], params["prediction_heads.0.bias"])
+    x_hats, rstds = [], []
+    for norm_slot, lin_slot in zip(NORM_IDS, LINEAR_IDS[1:]):
+        mean = x.mean(dim=-1, keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        x_hat = (x - mean) * rstd
+        x_hats.append(x_hat)
+        rstds.append(rstd[..., 0])
+        x = F.relu(x_hat * params[f"prediction_heads.{norm_slot}.weight"]
+                   + params[f"prediction_heads.{norm_slot}.bias"])
+        x = F.linear(x, params[f"prediction_heads.{lin_slot}.weight"],
+                     params[f"prediction_heads.{lin_slot}.bias"])
+    return x, x_hats, rstds
+
+
 def field(params, cfg, rays_o, rays_d, t):
     """NeRF.forward (model.py:553-594): returns means, covs, h, density, color, seg."""
     base_radius = 1 / (np.sqrt(3) * cfg["focal_length"])                       # :546

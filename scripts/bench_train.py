@@ -6,6 +6,7 @@ dev = torch.device('cuda:0')
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
 torch.manual_seed(0)
 model = NeRF().to(dev)
+model.train_precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 o = torch.randn(n, 3, device=dev); d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 def step():
@@ -20,5 +21,5 @@ K = 10
 for _ in range(K): l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"train step {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l.detach()):.4f}")
+print(f"train step [{model.train_precision} forward] {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l.detach()):.4f}")
 print(f"  algorithmic {3*601088*n*(S-1)/dt/1e12:.1f} TFLOP/s (fwd+dgrad+wgrad)")

@@ -2,7 +2,7 @@
 python scripts/isa_stats.py [mangled-substring] [-DNAME ...]"""
 import collections, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sub = "ILb0ELb1E"
+sub = "ILb0ELb1ELb0E"
 defs = []
 for a in sys.argv[1:]:
     if a.startswith("-D"): defs.append(a)

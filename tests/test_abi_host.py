@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(handle):
     for name in names:
         assert hasattr(handle, name), name
     assert set(_lib.EXPORTS) == set(names)
-    assert handle.nerf_hip_version() == 2
+    assert handle.nerf_hip_version() == _lib.ABI_VERSION == 3
     # packed image = 74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB
     assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4) + 68 * 16384
     assert handle.nerf_hip_grad_elements() == 304438
@@ -67,7 +67,7 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     args.n_rays = 0                       # empty batch is a no-op, not an error
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == 0
-    # unknown precision / split precision on the training forward: refused before any HIP call
+    # unknown precision: refused before any HIP call
     dummy = ctypes.c_void_p(16)
     args = _lib.RenderArgs()
     args.n_rays, args.num_samples = 8, 4
@@ -75,9 +75,7 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     args.precision = 7
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     assert b"precision" in handle.nerf_hip_last_error()
-    args.precision, args.train_workspace = _lib.PRECISIONS["f16x3"], dummy
-    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
-    assert b"fp32 only" in handle.nerf_hip_last_error()
+    assert handle.nerf_hip_build_flags() == b""          # the product build carries no experiment macro
     assert handle.nerf_hip_pack_weights(None, None, None) == -1
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()

@@ -31,3 +31,19 @@ def test_bench_constants_match_the_survey():
     import bench
     assert bench.FLOP_PER_SAMPLE == 2 * (96 * 256 + 4 * 256 * 256 + 256 * 54)
     assert (bench.IMAGE, bench.SAMPLES) == (800, 128)
+
+
+def test_defaults_are_the_reference_arithmetic_and_the_one_frame_partition(monkeypatch):
+    """The driver-checked line: fp32 (the reference's arithmetic) and, for N > 1, row blocks of ONE
+    frame (BASELINE config 4), 100 rows per GPU at N = 8."""
+    import bench
+    src = open(bench.__file__).read()
+    assert 'os.environ.get("NERF_BENCH_PRECISION", "fp32")' in src
+    assert 'choices=("weak", "strong"), default="strong"' in src
+    assert [bench.shard_rows(r, 8) for r in (0, 3, 7)] == [(0, 100), (300, 400), (700, 800)]
+    for world in (1, 2, 3, 4, 8):
+        blocks = [bench.shard_rows(r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == bench.IMAGE
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    assert bench.PRECISIONS["fp32"]["dtype"] == "f32"
+    assert isinstance(bench.cpu_model(), str) and bench.cpu_model()

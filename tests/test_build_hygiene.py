@@ -1,0 +1,95 @@
+"""CPU checks of the build itself (hipcc cross-compiles gfx950 without a GPU):
+* the emitted ISA obeys the inline-asm hazard rules of scripts/isa_hazards.py (hipcc inserts no wait
+  states inside asm statements, so the kernels may only touch registers there that a compiler-visible
+  instruction wrote last) — and the scanner does catch a violation when shown one;
+* a library compiled with a wrong-result experiment macro is refused by the default loader;
+* the Python mirror of the training workspace layout matches the library's."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scanner():
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(ROOT, "scripts", "isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_scanner_flags_unshielded_asm_accesses(tmp_path):
+    haz = _scanner()
+    bad = tmp_path / "bad.s"
+    bad.write_text("""
+_Zkernel:
+	v_mfma_f32_16x16x32_f16 v[12:15], v[84:87], v[68:71], v[12:15]
+	v_mfma_f32_16x16x32_f16 v[48:51], v[80:83], v[56:59], v[12:15]
+	;;#ASMSTART
+	v_fma_mix_f32 v12, v64, -1.0, v66 op_sel_hi:[1,0,0]
+	;;#ASMEND
+	v_readlane_b32 s4, v200, 1
+	;;#ASMSTART
+	s_mov_b32 m0, s9
+	global_load_lds_dwordx4 v138, s[4:5]
+	;;#ASMEND
+""")
+    rules = sorted({h[3] for h in haz.scan(str(bad))})
+    assert rules == ["R1-WAR", "R1-WAW", "R2", "R3"], rules
+    good = tmp_path / "good.s"
+    good.write_text("""
+_Zkernel:
+	v_mfma_f32_16x16x32_f16 v[48:51], v[80:83], v[56:59], v[12:15]
+	s_nop 6
+	v_max_f32_e32 v12, 0, v20
+	;;#ASMSTART
+	v_fma_mix_f32 v12, v64, -1.0, v12 op_sel_hi:[1,0,0]
+	;;#ASMEND
+	v_readlane_b32 s4, v200, 1
+	;;#ASMSTART
+	s_mov_b32 s20, m0
+	s_mov_b32 m0, s9
+	s_nop 2
+	global_load_lds_dwordx4 v138, s[4:5]
+	;;#ASMEND
+""")
+    assert haz.scan(str(good)) == []
+
+
+def test_kernels_obey_the_inline_asm_hazard_rules(tmp_path):
+    haz = _scanner()
+    for name in sorted(f for f in os.listdir(haz.CSRC) if f.endswith(".hip")):
+        out = str(tmp_path / (name + ".s"))
+        haz.compile_to_asm(os.path.join(haz.CSRC, name), out)
+        hits = haz.scan(out)
+        assert hits == [], hits[:3]
+
+
+def test_default_loader_refuses_an_experiment_build(tmp_path):
+    from nerf_amd import build as nerf_build
+    out = str(tmp_path / "libnerf_hip_exp.so")
+    nerf_build.build(out=out, defines=("NERF_EXP_NOBARRIER",))
+    code = ("import nerf_amd._lib as L, sys\n"
+            f"L.LIB_PATH = {out!r}\n"
+            "try:\n    L.lib()\nexcept RuntimeError as e:\n    print('REFUSED', e); sys.exit(0)\n"
+            "print('LOADED', L.build_flags())\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("NERF_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "NERF_EXP_NOBARRIER" in r.stdout, r.stdout + r.stderr
+    env["NERF_HIP_LIB"] = out                       # asked for by path: allowed (scripts/ablate.py)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "LOADED ['NERF_EXP_NOBARRIER']" in r.stdout, r.stdout + r.stderr
+
+
+def test_workspace_mirror_matches_the_library():
+    from nerf_amd import _lib, build as nerf_build, workspace as W
+    nerf_build.build()
+    lib = _lib.lib()
+    assert _lib.build_flags() == []
+    for n, S in ((1, 2), (3, 17), (5, 9), (130, 64), (256, 100), (4096, 64)):
+        assert W.train_layout(n, S)["total"] * 4 == lib.nerf_hip_train_workspace_bytes(n, S)
+    assert sorted(W.layer0_feature_order().tolist()) == list(range(96))

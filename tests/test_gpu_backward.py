@@ -25,10 +25,25 @@ def dev():
     return torch.device("cuda:0")
 
 
+_TRAIN_PRECISION = "fp32"
+
+
+@pytest.fixture(params=["fp32", "f16x3"], autouse=True)
+def train_precision(request):
+    """Every test runs with the training forward on both arithmetics (NeRF.train_precision; the
+    backward kernels are the same)."""
+    global _TRAIN_PRECISION
+    _TRAIN_PRECISION = request.param
+    yield request.param
+    _TRAIN_PRECISION = "fp32"
+
+
 def make_model(dev, params):
     from nerf_amd import NeRF
     model = NeRF()
     model.load_state_dict(params)
+    model.train_precision = _TRAIN_PRECISION
+    model.precision = _TRAIN_PRECISION            # no-grad launches of the same model: same arithmetic
     return model.to(dev)
 
 
@@ -66,8 +81,10 @@ def test_training_step_vs_reference(dev, name, scale):
         e = rel_err(p.grad.cpu(), ref)
         worst = max(worst, e)
         assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
-    if scale == 3.0:
+    if scale == 3.0 and _TRAIN_PRECISION == "fp32":
         assert worst <= 5e-6, worst               # no gate near zero on this fixture: exact parity
+    # (with the split-precision forward the saved activations differ from the reference's by ~3e-6,
+    #  which is enough to flip a gate or two even here: the noise-floor bound above applies)
     # RGB-only loss: the 50 segmentation rows of the last Linear get exactly zero gradient
     assert torch.count_nonzero(model.prediction_heads[15].weight.grad[4:]) == 0
     opt.step()

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n_rays,num_samples", [(256, 100), (4096, 64)])
-@pytest.mark.parametrize("mode", ["infer-fp32", "infer-f16x3", "train-fp32"])
+@pytest.mark.parametrize("mode", ["infer-fp32", "infer-f16x3", "train-fp32", "train-f16x3"])
 def test_forward_is_bitwise_reproducible(mode, n_rays, num_samples):
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")
@@ -23,6 +23,7 @@ def test_forward_is_bitwise_reproducible(mode, n_rays, num_samples):
     u = torch.rand(n_rays, num_samples, generator=g).to(dev)
     noise = torch.randn(n_rays, num_samples - 1, 1, generator=g).to(dev)
     kind, model.precision = mode.split("-")
+    model.train_precision = model.precision
     first = None
     for _ in range(12):
         with torch.set_grad_enabled(kind == "train"):
@@ -35,13 +36,15 @@ def test_forward_is_bitwise_reproducible(mode, n_rays, num_samples):
             assert torch.equal(cur, first), float((cur - first).abs().max())
 
 
-def test_training_step_gradients_are_bitwise_reproducible():
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+def test_training_step_gradients_are_bitwise_reproducible(train_precision):
     """Forward + backward of a 4096 x 64 batch (BASELINE config 5 shape), five times: loss and the
     flat 304,438-element gradient must not move by a bit."""
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = NeRF().to(dev)
+    model.train_precision = train_precision
     g = torch.Generator().manual_seed(7)
     n, S = 4096, 64
     o, d = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, 3, generator=g).to(dev)

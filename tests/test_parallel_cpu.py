@@ -124,3 +124,60 @@ def _gather_worker(rank, world, out_dir):
 
 def test_row_gather_with_uneven_blocks(tmp_path):
     run_ranks(_gather_worker, 2, str(tmp_path))
+
+
+class FlatNet(torch.nn.Module):
+    """A module whose backward hands out gradients as views of ONE flat vector, like the HIP
+    backward does (nerf_amd/backward.py): lets the in-place path of FlatGradientAllReduce run on CPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.net = make_net()
+        self.last_flat_grad = None
+
+    def forward(self, x):
+        return self.net(x)
+
+    def flatten_grads(self):
+        flat = torch.cat([p.grad.reshape(-1) for p in self.parameters()])
+        off = 0
+        for p in self.parameters():
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.last_flat_grad = flat
+
+
+def _uneven_worker(rank, world, out_dir, split):
+    """Uneven (and empty) shards: rank 0 takes `split` of the 64 examples, rank 1 the rest; each
+    weights its mean-loss gradient by local / global before the SUM all-reduce."""
+    net = FlatNet()
+    x, y = batch(0)
+    lo, hi = (0, split) if rank == 0 else (split, x.shape[0])
+    n = hi - lo
+    loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).sum() / max(3 * n, 1)        # mean, 0 for an empty shard
+    loss.backward()
+    net.flatten_grads()
+    reduce = parallel.FlatGradientAllReduce(net.parameters())
+    reduce(net.last_flat_grad, n / x.shape[0])
+    assert reduce.in_place_calls == 1                                      # no pack / unpack copies
+    assert all(p.grad.data_ptr() >= net.last_flat_grad.data_ptr() for p in net.parameters())
+    torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f"u{rank}.pt"))
+
+
+@pytest.mark.parametrize("split", [40, 63, 64])
+def test_weighted_all_reduce_handles_uneven_and_empty_shards(tmp_path, split):
+    run_ranks(_uneven_worker, 2, str(tmp_path), split)
+    net = make_net()
+    mse(net, batch(0)).backward()
+    for r in range(2):
+        got = torch.load(os.path.join(tmp_path, f"u{r}.pt"))
+        for a, p in zip(got, net.parameters()):
+            assert (a - p.grad).abs().max() <= 1e-6
+
+
+def test_all_reduce_falls_back_when_gradients_are_not_views():
+    net = make_net()
+    mse(net, batch(0)).backward()
+    reduce = parallel.FlatGradientAllReduce(net.parameters())
+    assert not reduce._aliases(torch.zeros(reduce.numel))
+    assert not reduce._aliases(None)
