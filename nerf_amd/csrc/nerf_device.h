@@ -11,6 +11,10 @@
 #include "nerf_layout.h"
 #include "nerf_common.h"
 
+#ifdef NERF_EXP_NOSETPRIO    /* bisect: every wave stays at priority 0 */
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#endif
+
 namespace nerf_device {
 
 using namespace nerf_layout;
@@ -341,6 +345,10 @@ __device__ __forceinline__ void halves_32(float v, float& lower, float& upper) {
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups of a sample
+#ifdef NERF_EXP_NOSWAP       /* bisect: ds_bpermute shuffles instead of the permlane swaps */
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+#endif
     float a, b;
     rows_16(v, a, b);
     v = a + b;
@@ -348,6 +356,10 @@ __device__ __forceinline__ float group_sum(float v) {      // over the 4 lane gr
     return a + b;
 }
 __device__ __forceinline__ float group_max(float v) {
+#ifdef NERF_EXP_NOSWAP
+    v = __builtin_fmaxf(v, __shfl_xor(v, 16));
+    return __builtin_fmaxf(v, __shfl_xor(v, 32));
+#endif
     float a, b;
     rows_16(v, a, b);
     v = __builtin_fmaxf(a, b);
@@ -445,22 +457,37 @@ __device__ __forceinline__ Gaussian frustum(const Ray& r, float t0, float t1, fl
     return g;
 }
 
-// sin(y) for |y| up to ~2e5 rad (the encoding's largest scale times the far plane) to ~1 ulp:
-// half-turn reduction in fp64 (n = rint(y / pi), r = y - n pi: the product is exact to 2e-11 at
-// these magnitudes), then an odd degree-11 minimax polynomial on [-pi/2, pi/2] (3e-11 fit error,
-// evaluated as r + r^3 s(r^2) so the leading term is exact) and the (-1)^n sign.  ~20 issue slots
-// against ~100+ for the general-purpose sinf with its Payne-Hanek path.
+// sin(y) for |y| up to ~2e5 rad (the encoding's largest scale times the far plane) to ~1 ulp
+// (max |error| 1.3e-7 against fp64 over +-2e5): half-turn reduction n = rint(y / pi),
+// r = y - n pi by three FMAs against pi split into three fp32 terms (Cody-Waite; each FMA rounds
+// once, and the first one cancels exactly the leading bits, so r carries ~1e-7 absolute error —
+// the same as the fp64 reduction it replaces, measured on 4e6 arguments), then an odd degree-11
+// minimax polynomial on [-pi/2, pi/2] (3e-11 fit error, evaluated as r + r^3 s(r^2) so the
+// leading term is exact) and the (-1)^n sign.  ~15 full-rate issue slots against ~100+ for the
+// general-purpose sinf with its Payne-Hanek path.
+// No fp64 anywhere in the kernels: the 24 reductions per sample used to be v_cvt/v_mul/v_rndne/
+// v_fma _f64 (quarter-rate, 16 lanes per pass); see DESIGN.md section 7 for what that was found to
+// do to a register's last 16 lanes when two waves of a SIMD ran their front ends together.
 __device__ __forceinline__ float sin_reduced(float y) {
+#ifdef NERF_EXP_SIN_F64      /* the former fp64 reduction, kept for the A/B of DESIGN.md section 7 */
     const double yd = (double)y;
-    const double n = __builtin_rint(yd * 0.31830988618379067);
-    const float r = (float)__builtin_fma(-n, 3.1415926535897931, yd);
+    const double nd = __builtin_rint(yd * 0.31830988618379067);
+    const float r = (float)__builtin_fma(-nd, 3.1415926535897931, yd);
+    const int parity = (int)nd & 1;
+#else
+    const float n = __builtin_rintf(y * 0.318309886f);
+    float r = __builtin_fmaf(-n, 3.1415927410125732f, y);
+    r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
+    r = __builtin_fmaf(-n, -3.4302490200117637e-15f, r);
+    const int parity = (int)n & 1;
+#endif
     const float u = r * r;
     float s = __builtin_fmaf(u, -2.3794713703943473e-08f, 2.7518855647935822e-06f);
     s = __builtin_fmaf(u, s, -0.00019840702862741812f);
     s = __builtin_fmaf(u, s, 0.008333329264456273f);
     s = __builtin_fmaf(u, s, -0.16666666541439012f);
     const float p = __builtin_fmaf(r * u, s, r);
-    return ((int)n & 1) ? -p : p;
+    return parity ? -p : p;
 }
 
 // exp for log-domain bookkeeping where ~2e-6 relative error is immaterial (segmentation
@@ -483,6 +510,11 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         act[12 + p] = damp * ((y + half_pi) * 1e-6f);
 #else
         const float damp = expf(-0.5f * yv);
+#ifdef NERF_EXP_ENC_NOP      /* bisect: a long gap between the transcendental and its consumers */
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(const_cast<float&>(damp)));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         act[p] = damp * sin_reduced(y);
         act[12 + p] = damp * sin_reduced(y + half_pi);
 #endif

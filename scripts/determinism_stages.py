@@ -72,7 +72,12 @@ for n, S in ((256, 100), (4096, 64)):
                         tile = row // 16
                         where.append(f"ray {tile // lay['chunks']} chunk {tile % lay['chunks']} j {row % 16}"
                                      f" cols {torch.nonzero(a[row] != b[row])[:6, 0].tolist()}")
-                line.append(f"{name}: {k} rows ({'; '.join(where)})")
+                diff = (a.double() - b.double()).abs()
+                diff = torch.where(torch.isnan(diff), torch.full_like(diff, float("inf")), diff)
+                r0 = rows[0]
+                c0 = int(torch.nonzero(a[r0] != b[r0])[0, 0])
+                line.append(f"{name}: {k} rows, max |diff| {float(diff.max()):.3e}, first: this {float(a[r0, c0])!r} "
+                            f"first-run {float(b[r0, c0])!r} ({'; '.join(where)})")
         nbad = int((cur_out != first_out).sum())
         total_bad += nbad + len(line)
         print(f"{n} x {S} run {r}: outputs differing {nbad}" + ("" if not line else "\n    " + "\n    ".join(line)),

@@ -16,6 +16,16 @@ The kernels therefore follow one rule, and this scan enforces it on the emitted 
   R4  a v_permlane*_swap inside asm does not read a VGPR written by a VALU less than 2 wait states
       earlier.
 
+and one rule that is not about asm but about an MI355X erratum measured by
+scripts/probes/pk_vs_mfma_coexec.hip (compiler-generated code must obey it too):
+
+  R5  no packed-fp32 instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) carries an op_sel bit,
+      i.e. none lets its LOW result select the HIGH register of a source pair: while the SIMD's
+      other wave executes v_mfma_f32_16x16x32_{f16,bf16}, such an instruction returns the low result
+      as if that operand were 0 in lanes 48-63 (22-25 % of the executions of v_pk_mul_f32).
+      op_sel_hi (the HIGH result selecting a LOW register) is unaffected.  The kernels are built
+      with -fno-slp-vectorize (nerf_amd/build.py), which is what keeps hipcc from producing the form.
+
 WINDOW = 20 covers the largest requirement of the MFMAs used here (8-pass XDL: 12).
 Usage: python scripts/isa_hazards.py [-DNAME ...]      exit code 1 when a rule is violated.
 """
@@ -28,10 +38,12 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf_amd", "csrc")
 WINDOW = 20
+sys.path.insert(0, ROOT)
+from nerf_amd.build import CODEGEN_FLAGS      # the product's code-generation flags, nothing else
 
 
 def compile_to_asm(src, out, defines=()):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-S", "--cuda-device-only",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unused-value",
            *[f"-D{d}" for d in defines], src, "-o", out]
     subprocess.run(cmd, check=True, capture_output=True)
@@ -91,6 +103,10 @@ def scan(path):
         if op == "s_nop":
             ws += int(ops[0]) + 1
             continue
+        if op.startswith("v_pk_") and op.endswith("_f32"):
+            sel = re.search(r"op_sel:\[([01,]+)\]", s)
+            if sel and "1" in sel.group(1):
+                found.append((kern, ln, s, "R5", "packed fp32 with an op_sel bit: wrong in lanes 48-63 beside 16x16x32 MFMAs"))
         if op.startswith("v_mfma"):
             for r in _vregs(ops[0]):
                 mfma_dst[r] = (ws, s)

@@ -9,7 +9,9 @@ for a in sys.argv[1:]:
     else: sub = a
 out = os.path.join(ROOT, "gpurun_out", "scratch", "isa.s")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+sys.path.insert(0, ROOT)
+from nerf_amd.build import CODEGEN_FLAGS
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-S", "--cuda-device-only",
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "nerf_amd", "csrc"),
                     "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", *defs,
                     os.path.join(ROOT, "nerf_amd", "csrc", "nerf_render.hip"), "-o", out],

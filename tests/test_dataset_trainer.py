@@ -83,3 +83,22 @@ def test_training_improves_held_out_psnr_and_writes_reference_files(tmp_path):
     assert json.load(open(os.path.join(tmp_path, "params.json")))["batch_size"] == 512
     state = torch.load(os.path.join(tmp_path, "model.pth"))
     assert list(state.keys())[:3] == ["rays_min", "rays_max", "prediction_heads.0.weight"]
+
+
+def test_load_scene_reads_the_tiny_nerf_layout(tmp_path):
+    """tiny_nerf_data.npz (examples/, not shipped: .MISSING_LARGE_BLOBS) holds images [V,H,W,3],
+    poses [V,4,4] and a scalar focal; the loader must take a file of that layout (any float dtype)."""
+    from nerf_amd import trainer as T
+    rng = np.random.default_rng(0)
+    images = rng.random((5, 10, 12, 3)).astype(np.float64)
+    poses = np.tile(np.eye(4, dtype=np.float32), (5, 1, 1))
+    poses[:, :3, 3] = rng.normal(size=(5, 3))
+    path = os.path.join(tmp_path, "tiny_nerf_like.npz")
+    np.savez(path, images=images, poses=poses, focal=np.array(138.88887889922103))
+    got_images, got_poses, focal = T.load_scene(path, "cpu")
+    assert got_images.dtype == torch.float32 and got_images.shape == (5, 10, 12, 3)
+    assert got_poses.dtype == torch.float32 and got_poses.shape == (5, 4, 4)
+    assert isinstance(focal, float) and abs(focal - 138.88887889922103) < 1e-9
+    assert torch.equal(got_images, torch.from_numpy(images.astype(np.float32)))
+    # the trainer's split: last view held out (train_conditional_nerf.py:89-95)
+    assert got_images[:-1].shape[0] == 4

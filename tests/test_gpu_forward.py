@@ -206,6 +206,26 @@ def test_full_frame_properties(dev):
     assert (seg_full.logsumexp(-1) <= 1e-3).all()
 
 
+def test_eight_row_shards_at_192_samples_vs_reference_and_whole_frame(dev):
+    """BASELINE config 4 as the 8-GPU job runs it: 800 x 800 x 192 in eight 100-row blocks.  The
+    assembled shards equal the whole-frame launch bit for bit, and the fixture crops of that frame
+    (G4, rendered by the reference) are met through the sharded path."""
+    g = load_golden("g4_crop800_x3")
+    model = make_model(dev, 3.0, focal_length=896.0)
+    cam_o, cam_r = g["camera_o"].to(dev), g["camera_r"].to(dev)
+    with torch.no_grad():
+        whole, whole_seg = model.render_image(cam_o, cam_r, 800, 800, 896.0, 192)
+        parts = [model.render_image(cam_o, cam_r, 800, 800, 896.0, 192, row_begin=100 * k,
+                                    row_end=100 * (k + 1)) for k in range(8)]
+    img = torch.cat([p[0] for p in parts], dim=1)
+    seg = torch.cat([p[1] for p in parts], dim=1)
+    assert torch.equal(img, whole) and torch.equal(seg, whole_seg)
+    r0, c0 = int(g["row0"]), int(g["col0"])
+    for nm, crop in (("center", img[0, r0:r0 + 16, c0:c0 + 16]), ("corner", img[0, :16, :16])):
+        ok = stable_rays(g[f"last_density_{nm}_192"])
+        assert (crop.reshape(-1, 3).cpu() - g[f"rgb_{nm}_192"])[ok].abs().max() <= 1e-5, nm
+
+
 def test_philox_path_statistics(dev):
     """In-kernel draws: reproducible for a fixed (seed, call), and statistically equal to the
     torch-draw path (mean image over many draws)."""

@@ -1,7 +1,9 @@
 """GPU test of the N>1 path with 2 ranks sharing the one MI355X of the test box (gloo for the
 rendezvous and the collective — RCCL refuses two ranks on one device; the 8-GPU RCCL run is the
 driver's scaling bench).  Checks with the real HIP kernels: row-sharded render == whole frame,
-all-reduced data-parallel gradients == single-process gradients of the concatenated batch."""
+all-reduced data-parallel gradients == single-process gradients of the concatenated batch for an
+UNEVEN split (weighted by local / global rays, reduced in place on the backward's flat vector), and
+the in-kernel draws of the two ranks differ."""
 import os
 
 import pytest
@@ -33,16 +35,25 @@ def _worker(rank, world, port, out_dir):
         with torch.no_grad():
             img, seg, rows = parallel.render_image_sharded(model, cam_o, cam_r, 37, 29, 32.0, 48,
                                                            gather=True)
-        # training: each rank its half of the rays, one flat all-reduce
+        # training: an uneven split of the rays (61 + 35), one flat all-reduce, in place
         torch.manual_seed(7)
         o, d, tgt = torch.randn(96, 3), torch.randn(96, 3), torch.rand(96, 3)
         u, noise = torch.rand(96, 40), torch.randn(96, 39, 1)
-        lo, hi = parallel.shard_items(96, rank, world)
+        lo, hi = (0, 61) if rank == 0 else (61, 96)
         pix, _ = model.render_rays(o[lo:hi].to(dev), d[lo:hi].to(dev), 40, randomly_sample=True,
                                    density_noise_std=1.0, u=u[lo:hi].to(dev), noise=noise[lo:hi].to(dev))
         ((pix[:, 0] - tgt[lo:hi].to(dev)) ** 2).mean().backward()
-        flat = parallel.FlatGradientAllReduce(model.parameters())()
-        torch.save(dict(img=img.cpu(), seg=seg.cpu(), rows=rows, flat=flat.cpu()),
+        reduce = parallel.FlatGradientAllReduce(model.parameters())
+        flat = reduce(model.last_flat_grad, (hi - lo) / 96)
+        assert reduce.in_place_calls == 1 and flat.data_ptr() == model.last_flat_grad.data_ptr()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        assert torch.equal(grads, flat)                  # p.grad are views of the reduced vector
+        # in-kernel (Philox) draws: the rank is part of the key, so the two ranks draw differently
+        model.rng = "philox"
+        rays_o = torch.zeros(32, 3, device=dev)
+        rays_d = torch.tensor([[1.0, 0.0, 0.0]], device=dev).repeat(32, 1)
+        t = model.fenceposts_used(rays_o, rays_d, 40, randomly_sample=True)
+        torch.save(dict(img=img.cpu(), seg=seg.cpu(), rows=rows, flat=flat.cpu(), t=t.cpu()),
                    os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -54,6 +65,8 @@ def test_two_ranks_on_one_gpu(tmp_path):
     r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
     assert r0["rows"] == (0, 19) and r1["rows"] == (19, 37)
     assert torch.equal(r0["img"], r1["img"]) and torch.equal(r0["flat"], r1["flat"])
+    # same seed, same rays, same launch count — different rank: different stratified draws
+    assert float(((r0["t"] - r1["t"]).abs() < 1e-6)[:, 1:-1].float().mean()) < 0.02
 
     from nerf_amd import NeRF
     from oracle import nerf_oracle as O
