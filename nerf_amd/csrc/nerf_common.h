@@ -144,51 +144,6 @@ inline const char* build_flags() {
 #ifdef NERF_EXP_NOPACKMOM
            "NERF_EXP_NOPACKMOM "
 #endif
-#ifdef NERF_EXP_ENC_NOP
-           "NERF_EXP_ENC_NOP "
-#endif
-#ifdef NERF_EXP_FE_WAITALL
-           "NERF_EXP_FE_WAITALL "
-#endif
-#ifdef NERF_EXP_MFMA_K16
-           "NERF_EXP_MFMA_K16 "
-#endif
-#ifdef NERF_EXP_NOSETPRIO
-           "NERF_EXP_NOSETPRIO "
-#endif
-#ifdef NERF_EXP_ONE_WG_PER_CU
-           "NERF_EXP_ONE_WG_PER_CU "
-#endif
-#ifdef NERF_EXP_NOMFMA
-           "NERF_EXP_NOMFMA "
-#endif
-#ifdef NERF_EXP_NOASM_RESID
-           "NERF_EXP_NOASM_RESID "
-#endif
-#ifdef NERF_EXP_NOSWAP
-           "NERF_EXP_NOSWAP "
-#endif
-#ifdef NERF_EXP_SKIP_MLP
-           "NERF_EXP_SKIP_MLP "
-#endif
-#ifdef NERF_EXP_NO_XHAT_STORE
-           "NERF_EXP_NO_XHAT_STORE "
-#endif
-#ifdef NERF_EXP_NOHOIST
-           "NERF_EXP_NOHOIST "
-#endif
-#ifdef NERF_EXP_VGPR256
-           "NERF_EXP_VGPR256 "
-#endif
-#ifdef NERF_EXP_CANARY
-           "NERF_EXP_CANARY "
-#endif
-#ifdef NERF_EXP_SIN_F64
-           "NERF_EXP_SIN_F64 "
-#endif
-#ifdef NERF_EXP_TRAIN_PLAINWAIT
-           "NERF_EXP_TRAIN_PLAINWAIT "
-#endif
 #ifdef NERF_EXP_WGRAD_NODMA
            "NERF_EXP_WGRAD_NODMA "
 #endif

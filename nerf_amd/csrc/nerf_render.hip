@@ -112,9 +112,7 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
             x[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
         }
     }
-#ifndef NERF_EXP_NO_XHAT_STORE   /* bisect: no x_hat stores (wrong gradients) */
     if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
-#endif
 }
 template <bool kTrain, bool kPacked = false>
 __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T) {
@@ -321,18 +319,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __fp16 q2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c) {
-#ifdef NERF_EXP_MFMA_K16     /* bisect: the pre-gfx950 instruction, two K=16 halves (wrong k order: wrong results) */
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
-    const h4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, c, 0, 0, 0), 0, 0, 0);
-#elif defined(NERF_EXP_NOMFMA)       /* bisect: no matrix instruction is issued (wrong results) */
-    f32x4 r = c;
-    asm volatile("" : "+v"(r.x) : "v"(a), "v"(b));       // keeps the operand reads alive
-    return r;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ h2 pack_rtz(float a, float b) {
     return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
@@ -347,16 +334,12 @@ __device__ __forceinline__ h2 pack_rtz(float a, float b) {
 // from the accumulators of MFMAs still in flight.
 template <int kHigh>
 __device__ __forceinline__ float residual(float x, const h2& pair) {
-#ifdef NERF_EXP_NOASM_RESID  /* bisect: compiler-generated residual (v_cvt_f32_f16 + v_sub_f32) */
-    return x - (float)(kHigh ? pair.y : pair.x);
-#else
     float r = x;
     if (kHigh)
         asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
     else
         asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
     return r;
-#endif
 }
 
 // (v | .) half of split8: one register tile -> its four hi and four lo halfs
@@ -601,18 +584,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
     f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators
     float* const ws = a.train_workspace;
-#ifdef NERF_EXP_VGPR256      /* bisect: allocate all 256 registers per wave */
-    asm volatile("v_mov_b32 v255, 0" ::: "v255");
-#endif
-#ifdef NERF_EXP_CANARY       /* diagnostic: loop-invariant per-lane registers, checked at every item */
-    uint32_t canary[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        canary[i] = 0xC0000000u | (i << 24) | (wave << 16) | (lane << 8) | (blockIdx.x & 255);
-        asm volatile("" : "+v"(canary[i]));
-    }
-    int item_no = 0;
-#endif
 
     // Inference: a wave owns a ray, walks its chunks in order and composites as it goes.
     // Training: compositing is a kernel of its own (nerf_composite_fwd_kernel), so the unit of
@@ -620,25 +591,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     // instead of 512 of them — and the network outputs / distances are saved for it.
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
         const int64_t unit = grp * kWavesPerWg + wave;
-#ifdef NERF_EXP_CANARY
-        if (kTrain && a.out_t != nullptr) {
-            uint32_t* dbg = (uint32_t*)a.out_t;         // [0] = record count, then 8-word records
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                asm volatile("" : "+v"(canary[i]));
-                const uint32_t want = 0xC0000000u | (i << 24) | (wave << 16) | (lane << 8) | (blockIdx.x & 255);
-                if (canary[i] != want) {
-                    const uint32_t k = atomicAdd(dbg, 1u);
-                    if (k < 4096) {
-                        uint32_t* r = dbg + 8 + 8 * k;
-                        r[0] = blockIdx.x, r[1] = wave, r[2] = lane, r[3] = i, r[4] = item_no, r[5] = canary[i], r[6] = want;
-                        r[7] = __builtin_amdgcn_s_getreg((23 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID... best effort
-                    }
-                }
-            }
-            ++item_no;
-        }
-#endif
         const int64_t slot = kTrain ? unit / chunks : unit;      // padded ray slot (workspace rows)
         int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
@@ -670,10 +622,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             const float t0 = fencepost(a, local, s);
             const float t1 = fencepost(a, local, s + 1);
             const float t2 = fencepost(a, local, s + 2);
-#ifdef NERF_EXP_FE_WAITALL   /* bisect: every outstanding load has landed before the front end runs */
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             const Gaussian gs = frustum(ray, t0, t1, a.base_radius_sq);
             float dist;
             {
@@ -682,13 +630,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             }
             {
                 float feat[64];
-#ifdef NERF_EXP_NOHOIST      /* bisect: the per-lane scale constants are rebuilt per item, not kept live */
-                int g_now = g;
-                asm volatile("" : "+v"(g_now));
-                encode(gs, g_now, feat);
-#else
                 encode(gs, g, feat);
-#endif
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t)
                     X[t] = f32x4{feat[4 * t], feat[4 * t + 1], feat[4 * t + 2], feat[4 * t + 3]};
@@ -698,9 +640,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
-#ifdef NERF_EXP_SKIP_MLP     /* bisect: front end + h stores only (wrong results) */
-            if (kTrain) continue;
-#endif
             float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;     // + ka.save.xhat[L]
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
@@ -1039,11 +978,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     const bool train = a.train_workspace != nullptr;
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
-#ifdef NERF_EXP_CANARY
-    if (false)
-#else
     if (train && (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr || a.out_t != nullptr))
-#endif
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean / out_cov / out_t are not produced by the training forward");
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave
     ka.groups = train ? ka.save.mp / 16 / kWavesPerWg : (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
@@ -1068,11 +1003,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
     const Kernel kernel = kernels[train][half][ps];
-#ifdef NERF_EXP_ONE_WG_PER_CU   /* bisect: 100 KiB of LDS per workgroup -> one workgroup per CU */
-    const int lds_bytes = 100 * 1024;
-#else
     const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
-#endif
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, &done[train][half][ps]);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs)
