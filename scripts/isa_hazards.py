@@ -39,11 +39,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf_amd", "csrc")
 WINDOW = 20
 sys.path.insert(0, ROOT)
-from nerf_amd.build import CODEGEN_FLAGS      # the product's code-generation flags, nothing else
+from nerf_amd.build import flags_for           # the product's code-generation flags, per file
 
 
 def compile_to_asm(src, out, defines=()):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-S", "--cuda-device-only",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags_for(src), "-S", "--cuda-device-only",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unused-value",
            *[f"-D{d}" for d in defines], src, "-o", out]
     subprocess.run(cmd, check=True, capture_output=True)

@@ -10,8 +10,8 @@ for a in sys.argv[1:]:
 out = os.path.join(ROOT, "gpurun_out", "scratch", "isa.s")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 sys.path.insert(0, ROOT)
-from nerf_amd.build import CODEGEN_FLAGS
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *CODEGEN_FLAGS, "-S", "--cuda-device-only",
+from nerf_amd.build import flags_for
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags_for("nerf_render.hip"), "-S", "--cuda-device-only",
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "nerf_amd", "csrc"),
                     "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", *defs,
                     os.path.join(ROOT, "nerf_amd", "csrc", "nerf_render.hip"), "-o", out],

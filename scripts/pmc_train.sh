@@ -1,12 +1,22 @@
 #!/bin/bash
-# usage: scripts/pmc_train.sh TAG KERNEL_SUBSTR   (GPU box) — SQ counters of one kernel of the training step
+# usage: scripts/pmc_train.sh TAG [fp32|f16x3]   (GPU box)
+# rocprofv3 of one training step (scripts/bench_train.py 4096 rays x 64, forward arithmetic as given):
+# one --kernel-trace --stats run, then one --pmc pass per counter group (never combined with a trace),
+# summarised per dispatch for the three MFMA kernels of the step into gpurun_out/TAG_{fwd,dgrad,wgrad}_pmc.json.
 set -e
-TAG=$1; KERN=${2:-nerf_wgrad_kernel}
+TAG=$1; PREC=${2:-fp32}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-B="python3 $PWD/scripts/bench_train.py 4096"
+B="python3 $PWD/scripts/bench_train.py 4096 $PREC"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- $B > $OUT/${TAG}_trace.log 2>&1
 pass() { n=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/${TAG}_$n -o run -- $B > $OUT/${TAG}_$n.log 2>&1; }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 pass d SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS
-python3 scripts/pmc_summary.py $OUT/${TAG}_a $OUT/${TAG}_d --kernel $KERN > $OUT/${TAG}_pmc.json
-cat $OUT/${TAG}_pmc.json
+pass b SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_CVT SQ_IFETCH SQ_ACTIVE_INST_SCA
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+summ() { python3 scripts/pmc_summary.py $OUT/${TAG}_a $OUT/${TAG}_d $OUT/${TAG}_b $OUT/${TAG}_fetch $OUT/${TAG}_write --kernel "$2" > $OUT/${TAG}_$1_pmc.json; }
+summ fwd "nerf_render_fwd_kernel<true"
+summ dgrad nerf_bwd_data_kernel
+summ wgrad nerf_wgrad_kernel
+grep -h "nerf_\|Name" $OUT/${TAG}_trace/*kernel_stats.csv | head -12
