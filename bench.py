@@ -103,12 +103,13 @@ def cpu_baseline(rows=32):
                       f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
 
 
-def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
+def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32"):
     """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
     backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
     from nerf_amd import NeRF
     torch.manual_seed(0)
     model = NeRF().to(dev)
+    model.train_precision = train_precision
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)
@@ -132,8 +133,54 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3):
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
-            "arithmetic": "training forward and data gradient on fp32 MFMA, weight gradient on bf16 "
-                          "triples (six bf16 MFMAs per product, fp32 accumulate)"}
+            "arithmetic": ("training forward on f16 triples (three f16 MFMAs per product), "
+                           if train_precision == "f16x3" else "training forward on fp32 MFMA, ")
+                          + "data gradient on fp32 MFMA, weight gradient on bf16 triples (six bf16 MFMAs per "
+                            "product); fp32 accumulate everywhere"}
+
+
+def legacy_workload_timing(dev, steps=3, warmup=1):
+    """Second workload: the same 800x800x128 frame through the LEGACY 8 x 256 network of the
+    reference's examples/nerf.pth (sin/cos encoding, skip trunk, view branch; 1,261,568 FLOP per sample,
+    fp32 MFMA; weights: the reference's trained Lego checkpoint, fixture G9).  Parity unpinned."""
+    import numpy as np
+    from nerf_amd import _lib
+    from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE as LEGACY_FLOP
+    path = os.path.join(ROOT, "tests", "golden", "g9_legacy_checkpoint.npz")
+    with np.load(path) as z:
+        params = {k[6:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("param.")}
+    model = LegacyNeRF8x256()
+    model.load_state_dict(params)
+    model = model.to(dev)
+    cam = torch.tensor(CAMERA) / torch.tensor(CAMERA).norm() * 4.03
+    cam_o, cam_r = look_at(tuple(cam.tolist()))
+    cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+    focal = 138.88887889922103 * IMAGE / 100.0
+
+    def step():
+        with torch.no_grad():
+            return model.render_image(cam_o, cam_r, IMAGE, IMAGE, focal, 2.0, 6.0, SAMPLES)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    _lib.timing(True)
+    _lib.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms, launches = _lib.timing_read(reset=True)
+    _lib.timing(False)
+    flop = IMAGE * IMAGE * SAMPLES * LEGACY_FLOP
+    achieved = flop / (kernel_ms * 1e-3) / 1e12
+    return {"workload": "legacy 8x256 network (examples/nerf.pth weights), 800x800, 128 samples/ray, "
+                        "sin/cos positional encoding, fp32 MFMA; parity unpinned",
+            "value": IMAGE * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "steps": steps,
+            "ms_per_step": dt * 1e3, "kernel_ms": kernel_ms, "flop_per_sample": LEGACY_FLOP,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_FP32_MFMA,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_FP32_MFMA}}
 
 
 def profiled_traffic(precision):
@@ -322,6 +369,8 @@ def main():
                 "roofline": roofline(other, o["rays_per_rank"], o["kernel_ms"], o["launches"], True),
             }
             line["train_step"] = train_step_timing(dev)
+            line["train_step_f16x3_forward"] = train_step_timing(dev, train_precision="f16x3")
+            line["legacy_network"] = legacy_workload_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if distributed:

@@ -186,6 +186,33 @@ typedef struct NerfHipResampleArgs {
 
 int nerf_hip_resample_pdf(const NerfHipResampleArgs* args, void* stream);
 
+/* The LEGACY (generation-A) network of examples/nerf.pth: sin/cos positional encoding, 8 x 256 trunk
+ * with a skip-concatenation, density head, 2 x 256 view branch, color head.  Its
+ * source is not in the reference repository; the structure is read off the checkpoint and the
+ * constants the checkpoint cannot settle are fields here.  PARITY UNPINNED: oracle/legacy_oracle.py
+ * holds the spec.  Call surface replaced: the notebook's NeRF(normalize_position=6.0).render_rays /
+ * render_image (examples/example.ipynb cells 6, 8).
+ * `params` of the pack routine: 44 DEVICE pointers, [W, b, gamma, beta] of block_0.{0,3,6,9} and
+ * block_1.{0,3,6,9}, then density.{weight,bias}, then block_2.{0,3}, then color.{weight,bias}. */
+#define NERF_HIP_LEGACY_PARAM_TENSORS 44
+#define NERF_HIP_LEGACY_FLOP_PER_SAMPLE 1261568
+
+typedef struct NerfHipLegacyArgs {
+    /* rays (arrays or cameras), num_samples = S sample POSITIONS per ray (S network evaluations),
+     * t_table [S] (+ u [n,S] for stratified sampling) or t_values [n,S], t_scale, noise [n,S],
+     * density_noise_std, packed (nerf_hip_legacy_pack_weights), rgb [n,3], out_weights [n,S],
+     * out_raw [n,S,4] = density | color logits.  seg, train_workspace, out_mean/cov/t, rng_mode,
+     * precision and base_radius_sq must be 0 / NULL. */
+    NerfHipRenderArgs render;
+    float normalize_position;   /* positions are divided by this before encoding (notebook: 6.0) */
+    float multiplier;           /* frequency f_k = multiplier * 2^k (chosen: pi)                 */
+    int32_t normalize_directions; /* encode d / |d| (chosen: 1)                                  */
+} NerfHipLegacyArgs;
+
+size_t nerf_hip_legacy_packed_bytes(void);
+int nerf_hip_legacy_pack_weights(const float* const* params, float* packed, void* stream);
+int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream);
+
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
  * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */

@@ -60,6 +60,13 @@ class ResampleArgs(ctypes.Structure):
                 ("t_union", _f32p)]
 
 
+class LegacyArgs(ctypes.Structure):
+    """Mirror of NerfHipLegacyArgs (include/nerf_hip.h)."""
+    _fields_ = [("render", RenderArgs), ("normalize_position", ctypes.c_float),
+                ("multiplier", ctypes.c_float), ("normalize_directions", ctypes.c_int32)]
+
+
+NUM_LEGACY_PARAM_TENSORS = 44
 _lib = None
 
 
@@ -92,6 +99,12 @@ def lib():
     handle.nerf_hip_gather_pixel_rays.argtypes = [ctypes.POINTER(GatherArgs), ctypes.c_void_p]
     handle.nerf_hip_resample_pdf.restype = ctypes.c_int
     handle.nerf_hip_resample_pdf.argtypes = [ctypes.POINTER(ResampleArgs), ctypes.c_void_p]
+    handle.nerf_hip_legacy_packed_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_legacy_pack_weights.restype = ctypes.c_int
+    handle.nerf_hip_legacy_pack_weights.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
+                                                    ctypes.c_void_p]
+    handle.nerf_hip_legacy_render_forward.restype = ctypes.c_int
+    handle.nerf_hip_legacy_render_forward.argtypes = [ctypes.POINTER(LegacyArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -113,7 +126,8 @@ def lib():
 EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "nerf_hip_packed_bytes",
            "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
            "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
-           "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_timing",
+           "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_legacy_packed_bytes",
+           "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward", "nerf_hip_timing",
            "nerf_hip_timing_read")
 
 

@@ -1,0 +1,405 @@
+// Fused render forward of the LEGACY (generation-A) network whose trained weights ship as
+// examples/nerf.pth: sin/cos positional encoding -> 8 x 256 trunk with a skip-concatenation ->
+// density head; view branch (2 x 256) -> color head; alpha compositing.  One persistent launch.
+//
+// PARITY UNPINNED: the network's source is not in the reference repository; the structure is
+// recovered from the checkpoint's tensor shapes and the unrecoverable constants are arguments
+// (oracle/legacy_oracle.py states every choice).  What IS the reference's:
+// the encoding layout (nerf/model.py:221-240), the compositing (nerf/model.py:438-469, :660) and
+// the call surface (examples/example.ipynb cells 6, 8).
+//
+// Same machinery as nerf_render.hip: a wave owns 16 samples x all 256 features in the fp32 MFMA
+// accumulator layout (nerf_layout.h), so a layer's output is the next layer's B operand without
+// leaving registers; weights stream L2 -> LDS through the 3-slot LDS-DMA ring (WeightPipe) in
+// consumption order, 157 stages of 16 KiB; exact-fp32 arithmetic (v_mfma_f32_16x16x4_f32).
+// Differences: [Linear, ReLU, LayerNorm] order (the LayerNorm is a VALU phase between two layers
+// here, not fused into the MFMA loops), two concatenation layers (the encodings stay in registers and
+// enter as extra k-groups), two one-tile heads, S samples = S evaluations at points.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerf_device.h"
+
+using namespace nerf_layout;
+using namespace nerf_device;
+
+namespace {
+
+constexpr int kPosFreqs = 10, kDirFreqs = 6;
+constexpr int kPosFeatures = 3 * 2 * kPosFreqs;          // 60: 15 per lane group, padded to 16
+constexpr int kDirFeatures = 3 * 2 * kDirFreqs;          // 36:  9 per lane group, padded to 12
+constexpr int kPosPerGroup = 15, kDirPerGroup = 9;
+constexpr int kPosTiles = 4, kDirTiles = 3;
+constexpr int kWide = 10;                                // LayerNorm layers: block_0 x4, block_1 x4, block_2 x2
+// stages per wide layer (k-groups of 16 input features; the concatenated encodings add 4 / 3)
+__host__ __device__ constexpr int wide_stages(int L) {
+    return L == 0 ? kPosTiles : (L == 4 ? 16 + kPosTiles : (L == 8 ? 16 + kDirTiles : 16));
+}
+// consumption order: L0..L7, density head, L8, L9, color head
+constexpr int kLegacyStages = 4 + 3 * 16 + 20 + 3 * 16 + 1 + 19 + 16 + 1;      // 157
+constexpr int kLegacyBlobFloats = kLegacyStages * kStageFloats;
+constexpr int kLegacySmallPerLayer = 3 * kHidden;                              // bias, gamma, beta
+constexpr int kHeadBiasFloats = 32;                                            // density [16], color [16]
+constexpr int kLegacySmallFloats = kWide * kLegacySmallPerLayer + kHeadBiasFloats;   // 7,712
+constexpr int kLegacyPackedFloats = kLegacyBlobFloats + kLegacySmallFloats;
+constexpr int kLegacySmallBytes = (kLegacySmallFloats * 4 + 127) / 128 * 128;
+constexpr int kLegacyLdsBytes = kRingBytes + kLegacySmallBytes;                // 79,104 B -> 2 workgroups / CU
+
+__host__ __device__ inline int stage_of_layer(int L) {      // first stage of wide layer L
+    int s = 0;
+    for (int i = 0; i < L; ++i) s += wide_stages(i);
+    return s + (L >= 8 ? 1 : 0);                             // the density head sits before layer 8
+}
+constexpr int kDensityStage = 4 + 3 * 16 + 20 + 3 * 16;      // 120
+constexpr int kColorStage = kLegacyStages - 1;
+
+struct LegacyKernelArgs {
+    NerfHipLegacyArgs l;
+    int32_t chunks;             // ceil(S / 16)
+    int64_t groups;             // ceil(n_rays / 4)
+};
+
+typedef WeightPipe<kLegacyStages> LegacyPipe;
+
+// sin(y) or cos(y) (shift) for |y| up to a few thousand rad: the half-turn reduction of
+// nerf_device.h: sin_reduced, with the cosine taken as sin(pi/2 - |r|) of the REDUCED argument
+// (adding pi/2 to y itself would cost an ulp of y: 6e-5 at y = 1600).
+__device__ __forceinline__ float sincos_reduced(float y, bool cosine) {
+    const float n = __builtin_rintf(y * 0.318309886f);
+    float r = __builtin_fmaf(-n, 3.1415927410125732f, y);
+    r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
+    r = __builtin_fmaf(-n, -3.4302490200117637e-15f, r);
+    if (cosine) r = 1.5707963267948966f - __builtin_fabsf(r);
+    const float u = r * r;
+    float s = __builtin_fmaf(u, -2.3794713703943473e-08f, 2.7518855647935822e-06f);
+    s = __builtin_fmaf(u, s, -0.00019840702862741812f);
+    s = __builtin_fmaf(u, s, 0.008333329264456273f);
+    s = __builtin_fmaf(u, s, -0.16666666541439012f);
+    const float p = __builtin_fmaf(r * u, s, r);
+    return ((int)n & 1) ? -p : p;
+}
+
+// Encoding feature f of [x: sin f_0..f_{F-1}, cos f_0..f_{F-1} | y: ... | z: ...] (nerf/model.py:233-240)
+template <int kFreqs>
+__device__ __forceinline__ float encoding_feature(int f, const float (&x)[3], float multiplier) {
+    const int coord = f / (2 * kFreqs), within = f - coord * 2 * kFreqs;
+    const bool cosine = within >= kFreqs;
+    const int k = cosine ? within - kFreqs : within;
+    const float v = coord == 0 ? x[0] : (coord == 1 ? x[1] : x[2]);
+    return sincos_reduced(v * (multiplier * (float)(1 << k)), cosine);
+}
+
+// LayerNorm(256, eps 1e-5, affine) of relu(acc) -> act (the next layer's B operands).
+// Lane (j, g) holds features 16 T + 4 g + r of sample j in acc[T][r]; exact two-pass variance.
+__device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const float* small_l, int g,
+                                                float (&act)[64]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
+            sum += act[4 * T + r];
+        }
+    const float mean = group_sum(sum) * (1.0f / 256.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float d = act[i] - mean;
+        sq = __builtin_fmaf(d, d, sq);
+    }
+    const float ve = group_sum(sq) * (1.0f / 256.0f) + 1e-5f;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
+    const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
+    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden + g * 64);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const f32x4 ga = gam[T], be = bet[T];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            act[4 * T + r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
+    }
+}
+
+__device__ __forceinline__ void load_bias(const float* small_l, int g, f32x4 (&acc)[16]) {
+    const f32x4* b = (const f32x4*)(small_l + g * 64);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) acc[T] = b[T];
+}
+
+// One-tile head (256 -> <= 16 outputs): one stage = 16 quads, quad t = the A operands of k-group t.
+__device__ __forceinline__ f32x4 head_layer(LegacyPipe& pipe, f32x4 acc, const float (&act)[64]) {
+    __builtin_amdgcn_s_setprio(0);
+    const f32x4* st = pipe.open_stage();
+    f32x4 a[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a[t] = st[t * 64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        acc = mfma4(a[t].x, act[4 * t], acc);
+        acc = mfma4(a[t].y, act[4 * t + 1], acc);
+        acc = mfma4(a[t].z, act[4 * t + 2], acc);
+        acc = mfma4(a[t].w, act[4 * t + 3], acc);
+    }
+    __builtin_amdgcn_s_setprio(2);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKernelArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipLegacyArgs& la = ka.l;
+    const NerfHipRenderArgs& a = la.render;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int S = a.num_samples;
+
+    float* small = (float*)(smem + kRingBytes);
+    for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyBlobFloats + i];
+    LegacyPipe pipe;
+    pipe.init(a.packed, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
+        int64_t local = grp * kWavesPerWg + wave;
+        const bool ray_ok = local < a.n_rays;
+        if (!ray_ok) local = a.n_rays - 1;
+        const Ray ray = load_ray(a, local);
+        // |d| (sample spacing in space) and the encoded view direction: once per ray
+        const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
+        float dir_act[64];
+        {
+            float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
+            if (la.normalize_directions) {
+                const float inv = 1.0f / dlen;
+                dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
+            }
+#pragma unroll
+            for (int q = 0; q < 4 * kDirTiles; ++q)
+                dir_act[q] = q < kDirPerGroup ? encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
+        }
+        RayAccum racc;
+        racc.reset();
+        for (int c = 0; c < ka.chunks; ++c) {
+            const int s = c * kSamplesPerWave + j;
+            const bool ok = s < S;
+            // sample positions: the fencepost routine of the main kernel on a caller-supplied table
+            // (linear in [near, far] for this network, Mildenhall et al. 2020), stratified by u, or
+            // explicit per-ray positions
+            const int sc = s < S - 1 ? s : S - 1;
+            const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
+            const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
+            float pos_act[64];
+            {
+#pragma clang fp contract(off)
+                const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
+                                    (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
+                                    (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
+#pragma unroll
+                for (int q = 0; q < 4 * kPosTiles; ++q)
+                    pos_act[q] = q < kPosPerGroup ? encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
+            }
+            f32x4 acc[16];
+            float act[64];
+            // ---- block_0 ----
+            load_bias(small, g, acc);
+            layer_wide<kPosTiles>(pipe, acc, pos_act);
+            relu_layer_norm(acc, small, g, act);
+#pragma unroll 1
+            for (int L = 1; L <= 3; ++L) {
+                const float* sl = small + L * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                layer_wide<16>(pipe, acc, act);
+                relu_layer_norm(acc, sl, g, act);
+            }
+            // ---- block_1: [hidden | encoded position] -> 256 ----
+            {
+                const float* sl = small + 4 * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                layer_wide<16>(pipe, acc, act);
+                layer_wide<kPosTiles>(pipe, acc, pos_act);
+                relu_layer_norm(acc, sl, g, act);
+            }
+#pragma unroll 1
+            for (int L = 5; L <= 7; ++L) {
+                const float* sl = small + L * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                layer_wide<16>(pipe, acc, act);
+                relu_layer_norm(acc, sl, g, act);
+            }
+            // ---- density head ----
+            const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
+            const f32x4 dens = head_layer(pipe, hb[g], act);
+            // ---- block_2: [hidden | encoded direction] -> 256 -> 256 ----
+            {
+                const float* sl = small + 8 * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                layer_wide<16>(pipe, acc, act);
+                layer_wide<kDirTiles>(pipe, acc, dir_act);
+                relu_layer_norm(acc, sl, g, act);
+                const float* sl9 = small + 9 * kLegacySmallPerLayer;
+                load_bias(sl9, g, acc);
+                layer_wide<16>(pipe, acc, act);
+                relu_layer_norm(acc, sl9, g, act);
+            }
+            const f32x4 col = head_layer(pipe, hb[4 + g], act);
+            // ---- compositing (nerf/model.py:438-469, :660): out[0] = (density, r, g, b) on lane group 0
+            f32x4 out[4];
+            out[0] = f32x4{dens.x, col.x, col.y, col.z};
+            out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float w = composite_chunk<false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
+            if (ray_ok && ok && g == 0) {
+                const int64_t smp = local * S + s;
+                if (a.out_weights != nullptr) a.out_weights[smp] = w;
+                if (a.out_raw != nullptr) {
+                    a.out_raw[smp * 4 + 0] = dens.x;
+                    a.out_raw[smp * 4 + 1] = col.x;
+                    a.out_raw[smp * 4 + 2] = col.y;
+                    a.out_raw[smp * 4 + 3] = col.z;
+                }
+            }
+        }
+        store_ray(a, local, ray_ok, lane, racc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter re-layout: the checkpoint's 44 tensors (oracle/legacy_oracle.py: state_dict_keys order)
+//   wide layer L = 0..9 (block_0 x4, block_1 x4, block_2 x2): params 4L .. 4L+3 = W, b, gamma, beta
+//   with the two heads spliced in: density W, b at 32, 33; block_2 at 34..41; color W, b at 42, 43
+// ---------------------------------------------------------------------------------------------
+struct LegacyPackArgs {
+    const float* p[NERF_HIP_LEGACY_PARAM_TENSORS];
+    float* packed;
+};
+
+__host__ __device__ inline int wide_param(int L) { return L < 8 ? 4 * L : 34 + 4 * (L - 8); }
+__host__ __device__ inline int wide_inputs(int L) { return L == 0 ? kPosFeatures : (L == 4 ? kHidden + kPosFeatures : (L == 8 ? kHidden + kDirFeatures : kHidden)); }
+
+__global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kLegacyPackedFloats) return;
+    float v = 0.f;
+    if (e < kLegacyBlobFloats) {
+        const int stage = e / kStageFloats;
+        const int in_stage = e - stage * kStageFloats;
+        const int quad = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int row = lane & 15, g = lane >> 4;
+        if (stage == kDensityStage || stage == kColorStage) {
+            // head: quad = k-group t, A[row = output][k = 16 t + 4 g + r]
+            const bool color = stage == kColorStage;
+            const int nout = color ? 3 : 1;
+            if (row < nout) v = pa.p[color ? 42 : 32][row * kHidden + 16 * quad + 4 * g + r];
+        } else {
+            int L = 0, first = 0;
+            for (L = 0; L < kWide; ++L) {
+                first = stage_of_layer(L);
+                if (stage >= first && stage < first + wide_stages(L)) break;
+            }
+            const int t = stage - first;                    // k-group within the layer
+            const int out = 16 * quad + row;
+            const int K = wide_inputs(L);
+            const float* W = pa.p[wide_param(L)];
+            int col = -1;
+            if (L == 0) {
+                const int q = 4 * t + r;
+                if (q < kPosPerGroup) col = kPosPerGroup * g + q;
+            } else if (t < 16) {
+                col = 16 * t + 4 * g + r;                   // hidden part: [hidden | encoding] order
+            } else {
+                const int q = 4 * (t - 16) + r;
+                if (L == 4 && q < kPosPerGroup) col = kHidden + kPosPerGroup * g + q;
+                if (L == 8 && q < kDirPerGroup) col = kHidden + kDirPerGroup * g + q;
+            }
+            if (col >= 0) v = W[out * K + col];
+        }
+    } else {
+        const int i = e - kLegacyBlobFloats;
+        if (i < kWide * kLegacySmallPerLayer) {
+            const int L = i / kLegacySmallPerLayer, rem = i % kLegacySmallPerLayer;
+            const int which = rem / kHidden, q = rem % kHidden;     // bias, gamma, beta in [g][T][reg] order
+            const int g = q / 64, T = (q % 64) / 4, reg = q & 3;
+            v = pa.p[wide_param(L) + 1 + which][16 * T + 4 * g + reg];
+        } else {
+            const int q = i - kWide * kLegacySmallPerLayer;          // head biases [head][g][reg]: row 4 g + reg
+            const int head = q / 16, n = q % 16;
+            if (head == 0 && n < 1) v = pa.p[33][n];
+            if (head == 1 && n < 3) v = pa.p[43][n];
+        }
+    }
+    pa.packed[e] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nerf_hip_legacy_packed_bytes(void) { return (size_t)kLegacyPackedFloats * sizeof(float); }
+
+int nerf_hip_legacy_pack_weights(const float* const* params, float* packed, void* stream) {
+    if (params == nullptr || packed == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_pack_weights: null pointer");
+    LegacyPackArgs pa;
+    for (int i = 0; i < NERF_HIP_LEGACY_PARAM_TENSORS; ++i) {
+        if (params[i] == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "legacy_pack_weights: null tensor");
+        pa.p[i] = params[i];
+    }
+    pa.packed = packed;
+    const int threads = 256, blocks = (kLegacyPackedFloats + threads - 1) / threads;
+    hipLaunchKernelGGL(nerf_legacy_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, pa);
+    return nerf_common::check_hip(hipGetLastError(), "legacy_pack_weights launch");
+}
+
+int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) {
+    if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: null args");
+    const NerfHipRenderArgs& a = args->render;
+    if (a.n_rays == 0) return NERF_HIP_OK;
+    if (a.n_rays < 0 || a.num_samples < 2 || a.num_samples > 4096)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: n_rays / num_samples out of range");
+    if (a.packed == nullptr || a.rgb == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: packed / rgb is null");
+    const bool arrays = a.rays_o != nullptr && a.rays_d != nullptr;
+    const bool cameras = a.camera_o != nullptr && a.camera_r != nullptr && a.image_h > 0 && a.image_w > 0 &&
+                         a.focal_length != 0.f;
+    if (!arrays && !cameras)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: neither ray arrays nor cameras given");
+    if ((a.rays_o == nullptr) != (a.rays_d == nullptr))
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: rays_o and rays_d must come together");
+    if (a.seg != nullptr || a.train_workspace != nullptr || a.out_mean != nullptr || a.out_cov != nullptr ||
+        a.out_t != nullptr || a.rng_mode != 0)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: seg / training / Gaussian outputs / in-kernel draws do not exist for this network");
+    if (a.t_values == nullptr && a.t_table == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: t_table / t_values is null");
+    if (!(args->normalize_position > 0.f))
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: normalize_position must be positive");
+
+    LegacyKernelArgs ka;
+    ka.l = *args;
+    ka.chunks = (a.num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
+    ka.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+    int device = 0, cus = 0;
+    int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
+    if (rc) return rc;
+    rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
+                                "hipDeviceGetAttribute");
+    if (rc) return rc;
+    static unsigned done = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel, kLegacyLdsBytes, device, &done);
+    if (rc) return rc;
+    int64_t grid = (int64_t)cus * 2;
+    if (grid > ka.groups) grid = ka.groups;
+    hipStream_t st = (hipStream_t)stream;
+    nerf_common::Timing::before(st);
+    hipLaunchKernelGGL(nerf_legacy_fwd_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    rc = nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
+    nerf_common::Timing::after(st);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""The LEGACY (generation-A) network of ``examples/nerf.pth`` on the MI355X renderer.
+
+The reference ships trained Lego weights for a vanilla-NeRF-style network (sin/cos positional
+encoding, 8 x 256 trunk with a skip-concatenation, density head, 2 x 256 view branch, color head)
+whose SOURCE is no longer in the repository (SURVEY.md sections 0.4, 2.3).  This module gives that
+checkpoint a home: the module tree is the one its 44 tensor names describe, so
+``load_state_dict(torch.load("examples/nerf.pth"))`` works, and the call surface is the notebook's
+(examples/example.ipynb cells 6, 8):
+
+    NeRF(normalize_position=6.0)
+    render_rays(rays_o, rays_d, near, far, num_samples, randomly_sample, density_noise_std) -> [N, 3]
+    render_image(camera_o, camera_r, H, W, focal, near, far, num_samples)                  -> [B, H, W, 3]
+
+PARITY UNPINNED.  What the checkpoint cannot settle — activation (ReLU), frequency multiplier (pi),
+concatenation order ([hidden, encoding]), normalised view directions — are stated choices that
+``oracle/legacy_oracle.py`` restates on the CPU and SURVEY.md's probe found to render the Lego
+scene; they are constructor keywords.  Everything render_rays computes is ONE fused HIP launch
+(``nerf_hip_legacy_render_forward``, nerf_amd/csrc/nerf_legacy.hip); inference only.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .model import NeRF as _GenerationC, _require_device
+
+__all__ = ["LegacyNeRF8x256"]
+
+FLOP_PER_SAMPLE = 1261568          # 2 x (60 + 3*256 + 316 + 3*256 + 1 + 292 + 256 + 3) x 256: SURVEY.md section 2.3
+
+
+def _block(first_inputs, layers):
+    mods = []
+    for i in range(layers):
+        mods += [nn.Linear(first_inputs if i == 0 else 256, 256), nn.ReLU(), nn.LayerNorm(256)]
+    return nn.Sequential(*mods)
+
+
+class LegacyNeRF8x256(nn.Module):
+    def __init__(self, normalize_position=6.0, multiplier=math.pi, normalize_directions=True):
+        super().__init__()
+        self.normalize_position = float(normalize_position)
+        self.multiplier = float(multiplier)
+        self.normalize_directions = bool(normalize_directions)
+        # the checkpoint's tree: block_0.{0,3,6,9} Linear, .{2,5,8,11} LayerNorm, slots 1,4,7,10 parameter-less
+        self.density = nn.Linear(256, 1)
+        self.color = nn.Linear(256, 3)
+        self.block_0 = _block(60, 4)
+        self.block_1 = _block(256 + 60, 4)
+        self.block_2 = _block(256 + 36, 2)
+        self._packed = None
+        self._packed_key = None
+        self._tables = {}
+
+    # pose helpers of the reference's class, unchanged (nerf/model.py:243-367)
+    generate_rays = staticmethod(_GenerationC.generate_rays)
+    rays_to_world_coordinates = staticmethod(_GenerationC.rays_to_world_coordinates)
+    get_rotation_matrix = staticmethod(_GenerationC.get_rotation_matrix)
+    spherical_to_cartesian = staticmethod(_GenerationC.spherical_to_cartesian)
+
+    def _param_list(self):
+        """The 44 tensors in the order nerf_hip_legacy_pack_weights takes them."""
+        order = []
+        for block in (self.block_0, self.block_1):
+            for slot in (0, 3, 6, 9):
+                order += [block[slot].weight, block[slot].bias, block[slot + 2].weight, block[slot + 2].bias]
+        order += [self.density.weight, self.density.bias]
+        for slot in (0, 3):
+            order += [self.block_2[slot].weight, self.block_2[slot].bias,
+                      self.block_2[slot + 2].weight, self.block_2[slot + 2].bias]
+        return order + [self.color.weight, self.color.bias]
+
+    def packed_parameters(self):
+        params = self._param_list()
+        dev = params[0].device
+        for p in params:
+            _require_device(p, "parameter")
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed_key != key or self._packed.device != dev:
+            lib = _lib.lib()
+            keep = [p.detach().contiguous() for p in params]
+            ptrs = (ctypes.c_void_p * _lib.NUM_LEGACY_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
+            packed = torch.empty(lib.nerf_hip_legacy_packed_bytes() // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(lib.nerf_hip_legacy_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
+                           "nerf_hip_legacy_pack_weights")
+            self._packed, self._packed_key = packed, key
+        return self._packed
+
+    def _table(self, near, far, num_samples, device):
+        """Linear sample positions in [near, far] (torch.linspace on the CPU, cached on the device)."""
+        key = (float(near), float(far), int(num_samples), str(device))
+        if key not in self._tables:
+            self._tables[key] = torch.linspace(float(near), float(far), num_samples,
+                                               dtype=torch.float32).to(device)
+        return self._tables[key]
+
+    def _launch(self, n_rays, num_samples, device, near, far, *, rays_o=None, rays_d=None, cameras=None,
+                ray_begin=0, u=None, noise=None, density_noise_std=0.0, rgb=None, per_sample=False):
+        lib = _lib.lib()
+        packed = self.packed_parameters()
+        if rgb is None:
+            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
+        raw = weights = None
+        if per_sample:
+            raw = torch.empty(n_rays, num_samples, 4, dtype=torch.float32, device=device)
+            weights = torch.empty(n_rays, num_samples, dtype=torch.float32, device=device)
+        table = self._table(near, far, num_samples, device)
+        args = _lib.LegacyArgs()
+        r = args.render
+        r.rays_o, r.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
+        if cameras is not None:
+            cam_o, cam_r, image_h, image_w, focal = cameras
+            r.camera_o, r.camera_r = _lib.ptr(cam_o), _lib.ptr(cam_r)
+            r.image_h, r.image_w, r.focal_length = image_h, image_w, float(focal)
+        r.ray_begin, r.n_rays, r.num_samples = int(ray_begin), int(n_rays), int(num_samples)
+        r.t_table, r.t_scale = _lib.ptr(table), 1.0
+        r.u, r.noise = _lib.ptr(u), _lib.ptr(noise)
+        r.density_noise_std = float(density_noise_std)
+        r.packed, r.rgb = _lib.ptr(packed), _lib.ptr(rgb)
+        r.out_raw, r.out_weights = _lib.ptr(raw), _lib.ptr(weights)
+        args.normalize_position = self.normalize_position
+        args.multiplier = self.multiplier
+        args.normalize_directions = 1 if self.normalize_directions else 0
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nerf_hip_legacy_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_legacy_render_forward")
+        return rgb, raw, weights
+
+    def render_rays(self, rays_o, rays_d, near, far, num_samples, randomly_sample=False,
+                    density_noise_std=0.0, u=None, noise=None, per_sample=False):
+        """Pixels [N, 3] of a batch of rays (the notebook's signature, cell 8).  ``u`` [N, S] /
+        ``noise`` [N, S] replace the torch draws; ``per_sample`` also returns (density | color
+        logits [N, S, 4], compositing weights [N, S])."""
+        _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
+        lead = rays_o.shape[:-1]
+        flat_o = rays_o.detach().reshape(-1, 3).contiguous()
+        flat_d = rays_d.detach().reshape(-1, 3).contiguous()
+        n_rays, dev = flat_o.shape[0], flat_o.device
+        if u is None and randomly_sample:
+            u = torch.rand(n_rays, num_samples, dtype=torch.float32, device=dev)
+        if noise is None and density_noise_std != 0.0:
+            noise = torch.randn(n_rays, num_samples, dtype=torch.float32, device=dev)
+        u = None if u is None else u.detach().reshape(n_rays, num_samples).contiguous()
+        noise = None if noise is None else noise.detach().reshape(n_rays, num_samples).contiguous()
+        rgb, raw, weights = self._launch(n_rays, num_samples, dev, near, far, rays_o=flat_o, rays_d=flat_d,
+                                         u=u, noise=noise, density_noise_std=density_noise_std,
+                                         per_sample=per_sample)
+        rgb = rgb.reshape(*lead, 3)
+        return (rgb, raw, weights) if per_sample else rgb
+
+    def render_image(self, camera_o, camera_r, image_h, image_w, focal_length, near, far, num_samples,
+                     row_begin=0, row_end=None):
+        """Frames [B, rows, W, 3]: one launch per frame, rays generated inside the kernel from the
+        poses (the notebook's signature, cell 8; ``row_begin``/``row_end`` as in the generation-C class)."""
+        _require_device(camera_o, "camera_o"), _require_device(camera_r, "camera_r")
+        device, batch = camera_o.device, camera_o.shape[0]
+        row_end = image_h if row_end is None else row_end
+        rows = row_end - row_begin
+        cameras = (camera_o.detach().contiguous(), camera_r.detach().contiguous(), image_h, image_w, focal_length)
+        out = torch.empty(batch, rows, image_w, 3, dtype=torch.float32, device=device)
+        for b in range(batch):
+            n_rays = rows * image_w
+            self._launch(n_rays, num_samples, device, near, far, cameras=cameras,
+                         ray_begin=(b * image_h + row_begin) * image_w, rgb=out[b].reshape(n_rays, 3))
+        return out
