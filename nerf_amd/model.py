@@ -264,13 +264,19 @@ class NeRF(nn.Module):
             self._packed, self._packed_key = packed, key
         return self._packed
 
-    def _check_f16x3_range(self):
+    def _check_f16x3_range(self, training=False):
         """The split-precision kernel holds 2^8 * w and 2^4 * relu(gamma * x_hat + beta) as f16
         pairs (|x_hat| < 16 for 256 features); refuse parameters that would leave the f16 range
-        instead of saturating silently.  Checked once per parameter version."""
+        instead of saturating silently.  Checked once per parameter version for inference launches;
+        a training forward (new parameter version every optimiser step, and the check is a device ->
+        host copy) re-checks every 64th step: a weight does not grow from O(0.1) to 256 in between."""
         key = self._packed_key
         if getattr(self, "_f16x3_checked", None) == key:
             return
+        if training:
+            self._f16x3_train_calls = getattr(self, "_f16x3_train_calls", -1) + 1
+            if self._f16x3_train_calls % 64 != 0:
+                return
         heads = self.prediction_heads
         with torch.no_grad():                       # one device -> host copy per parameter version
             w_dev = torch.stack([heads[i].weight.abs().max() for i in (0, 3, 6, 9, 12, 15)]).max()
@@ -312,7 +318,7 @@ class NeRF(nn.Module):
             raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {which!r}")
         args.precision = _lib.PRECISIONS[which]
         if args.precision == _lib.PRECISIONS["f16x3"]:
-            self._check_f16x3_range()
+            self._check_f16x3_range(training=train_workspace is not None)
 
     def _scratch(self, nbytes, device):
         """Cached scratch buffer for the backward's partial slabs."""
