@@ -37,6 +37,7 @@ class RenderRaysFunction(torch.autograd.Function):
         ctx.call = (rays_o, rays_d, num_samples, u, noise, density_noise_std, rng_mode, rng_state,
                     t_values)
         ctx.workspace = workspace
+        ctx.precision = _lib.PRECISIONS[model.train_precision]   # the data gradient uses the same arithmetic
         ctx.packed = model.packed_parameters()      # the image this forward used
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(rgb, seg)
@@ -60,7 +61,8 @@ class RenderRaysFunction(torch.autograd.Function):
         args = _lib.BackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, u=u,
                          t_values=t_values, noise=noise, density_noise_std=std, rng_mode=rng_mode, rng_state=rng_state,
-                         packed=ctx.packed, rgb=rgb, seg=seg, train_workspace=ctx.workspace)
+                         packed=ctx.packed, rgb=rgb, seg=seg, train_workspace=ctx.workspace,
+                         precision=ctx.precision)
         grad = torch.empty(lib.nerf_hip_grad_elements(), dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
         args.d_rgb, args.d_seg = _lib.ptr(d_rgb), _lib.ptr(d_seg)

@@ -92,10 +92,14 @@ struct BwdHook {
 // LayerNorm + ReLU backward for hidden layer L on the register tile.
 //   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
 //   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
+//   kScaled (split-precision chain): acc holds dL/dx times the per-sample power of two `unscale`
+//   undoes (the B operands were scaled into the f16 range, the weights carry 2^kWScaleLog2)
+template <bool kScaled = false>
 __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
                                                     f32x4 (&acc)[16], float (&act)[64],
                                                     const f32x4 (&xh)[16], float rstd,
-                                                    float* dy_row, float* gb_l, GammaBetaTurn& turn) {
+                                                    float* dy_row, float* gb_l, GammaBetaTurn& turn,
+                                                    float unscale = 1.0f) {
     const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     float s1 = 0.f, s2 = 0.f;
@@ -106,7 +110,9 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float z = __builtin_fmaf(xh[T][r], ga[r], be[r]);
-            const float dz = z > 0.f ? acc[T][r] : 0.f;
+            float dz;               // (if constexpr: a ?: on kScaled costs the fp32 kernel 60 spilled registers)
+            if constexpr (kScaled) dz = z > 0.f ? acc[T][r] * unscale : 0.f;
+            else dz = z > 0.f ? acc[T][r] : 0.f;
             // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
             const float rb = row_sum(dz);
             const float rg = row_sum(dz * xh[T][r]);
@@ -260,6 +266,30 @@ __global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs b
         }
 }
 
+// Split-precision data gradient: a sample's dY row becomes f16 pairs after an exact per-sample
+// power-of-two scaling that puts its largest magnitude in [2^12, 2^13) (the chain is linear in dY,
+// so the scale is undone on the accumulators; f16 keeps 11 bits per half down to 2^-14, i.e. an
+// element 2^-16 of the row's largest still has all 22 bits).  Returns the scale; `unscale` also
+// removes the weights' 2^kWScaleLog2.
+__device__ __forceinline__ float row_scale(float amax_lane, float& unscale) {
+    const float amax = group_max(amax_lane);
+    uint32_t e = __builtin_bit_cast(uint32_t, amax) >> 23;            // amax >= 0
+    e = e < 32u ? 32u : e;                                            // rows below 2^-95: treated as 2^-95
+    unscale = __builtin_bit_cast(float, (e - 12u - (uint32_t)kWScaleLog2) << 23);
+    return __builtin_bit_cast(float, (266u - e) << 23);               // 2^(12 - (e - 127))
+}
+__device__ __forceinline__ float abs_max4(float m, const f32x4& v) {
+    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)));
+    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+}
+
+// Stage hook of the split-precision loops: only the wave-ordered gamma/beta adds (the x_hat
+// prefetch is issued before the loop: a 0.2 us stage cannot hide an HBM load behind one hand-over).
+struct TurnHook {
+    GammaBetaTurn& turn;
+    __device__ __forceinline__ void operator()(int t) const { turn(t); }
+};
+
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ba.a;
@@ -281,6 +311,11 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     pipe.issue();
     __syncthreads();
 
+#ifdef NERF_BWD_STAGGER
+    if (blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < NERF_BWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     float act[64];
     f32x4 acc[16];
     GammaBetaTurn turn;
@@ -323,6 +358,138 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             }
             layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
                                 gb, turn);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < kWavesPerWg; ++t) {       // the last chunk's layer-0 partials, in wave order
+        __syncthreads();
+        turn(t);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+}
+
+// timing experiments of the split-precision chain (wrong results; listed by nerf_hip_build_flags)
+#ifdef NERF_EXP_BWD_NOXHAT
+#define BWD_XHAT(p) (f32x4{0.5f, -0.25f, 0.125f, 1.0f})
+constexpr int kYoungerL5 = 0, kYoungerHidden = 16;
+#else
+#define BWD_XHAT(p) (*(const f32x4*)(p))
+#ifdef NERF_EXP_BWD_NOLN
+constexpr int kYoungerL5 = 17, kYoungerHidden = 17;
+#else
+constexpr int kYoungerL5 = 17, kYoungerHidden = 33;
+#endif
+#endif
+#ifdef NERF_EXP_BWD_NOMFMA
+#define BWD_MFMA(x) ((void)0)
+#else
+#define BWD_MFMA(x) x
+#endif
+// The same chain in split-precision arithmetic (see row_scale above).
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* const ws = a.train_workspace;
+    float* const gb = (float*)(smem + kRingBytes + kSmallLdsBytes);
+
+    {
+        stage_small_image(a.packed + kBlobFloats, (float*)(smem + kRingBytes));
+        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+    }
+    const float* small = (const float*)(smem + kRingBytes);
+
+    BwdPipe pipe;
+    pipe.init(a.packed + kBwdHBlobOffset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+#ifdef NERF_BWD_STAGGER
+    if (blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < NERF_BWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    // one (padded ray, chunk) item per wave: dL/d(out) of every sample was written by
+    // nerf_composite_bwd_kernel (the suffix sum along the ray lives there), so the chunks of a ray
+    // are independent here and a small batch still fills the chip
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
+        {
+            const int64_t sp = tile * 16 + j;
+            f32x4 dout[4];
+            {
+                const float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
+            }
+
+            f32x4 xh[16];
+            float rstd;
+            // x_hat / 1/std of layer 4 first: 17 loads that fly under the 4 stages of layer 5
+            const float* xrow = ws + ba.L.xhat[4] + sp * kHidden + 4 * g;
+#pragma unroll
+            for (int T = 0; T < 16; ++T) xh[T] = BWD_XHAT(xrow + T * 16);
+            rstd = ws[ba.L.rstd[4] + sp];
+            float unscale;
+            {
+                float m = 0.f;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) m = abs_max4(m, dout[T]);
+                const float sc = row_scale(m, unscale);
+                h8 bh[2], bl[2];
+                split8(dout[0] * sc, dout[1] * sc, bh[0], bl[0]);
+                split8(dout[2] * sc, dout[3] * sc, bh[1], bl[1]);
+#pragma unroll
+                for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                BWD_MFMA((layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn})));
+            }
+#pragma unroll 1
+            for (int L = 4; L >= 0; --L) {
+#ifdef NERF_EXP_BWD_NOLN
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[4 * T + r] = acc[T][r] * unscale + xh[T][r] * rstd;
+#else
+                layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
+                                          ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
+                                          turn, unscale);
+#endif
+                if (L == 0) break;
+                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
+                // all of them younger than the two stages this layer's loop opens first
+                const float* xrow_n = ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g;
+#pragma unroll
+                for (int T = 0; T < 16; ++T) xh[T] = BWD_XHAT(xrow_n + T * 16);
+                rstd = ws[ba.L.rstd[L - 1] + sp];
+                float m = 0.f;
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    m = abs_max4(m, f32x4{act[4 * T], act[4 * T + 1], act[4 * T + 2], act[4 * T + 3]});
+                const float sc = row_scale(m, unscale);
+                h8 bh[8], bl[8];
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int t0 = 8 * mb, t1 = 8 * mb + 4;
+                    split8(f32x4{act[t0], act[t0 + 1], act[t0 + 2], act[t0 + 3]} * sc,
+                           f32x4{act[t1], act[t1 + 1], act[t1 + 2], act[t1 + 3]} * sc, bh[mb], bl[mb]);
+                }
+#pragma unroll
+                for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                BWD_MFMA((layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, TurnHook{turn})));
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -888,7 +1055,12 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
     static unsigned done_data = 0, done_wgrad = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_kernel, kBwdLdsBytes, device, &done_data);
+    const bool half = a.precision == NERF_HIP_PRECISION_F16X3;   // the arithmetic of the training forward
+    static unsigned done_data_h = 0;
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_h_kernel, kBwdLdsBytes, device,
+                                                &done_data_h)
+              : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_kernel, kBwdLdsBytes, device,
+                                                &done_data);
     if (rc) return rc;
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_kernel, 2 * ShapeHid::kTileBytes, device,
                                          &done_wgrad);
@@ -900,7 +1072,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
 
     hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                        dim3(256), 0, st, ba);
-    hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
 #ifdef NERF_EXP_WGRAD_HID_ONLY   /* timing experiment: hidden layers only (wrong gradients) */
     hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 4), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
 #else

@@ -156,6 +156,18 @@ inline const char* build_flags() {
 #ifdef NERF_STAGGER
            "NERF_STAGGER "
 #endif
+#ifdef NERF_BWD_STAGGER
+           "NERF_BWD_STAGGER "
+#endif
+#ifdef NERF_EXP_BWD_NOXHAT
+           "NERF_EXP_BWD_NOXHAT "
+#endif
+#ifdef NERF_EXP_BWD_NOLN
+           "NERF_EXP_BWD_NOLN "
+#endif
+#ifdef NERF_EXP_BWD_NOMFMA
+           "NERF_EXP_BWD_NOMFMA "
+#endif
         ;
 }
 

@@ -164,12 +164,8 @@ struct WeightPipe {
     template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
 #ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
-        static_assert(kYounger >= 0 && kYounger <= 4, "vmcnt immediate");
-        if (kYounger == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if (kYounger == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        static_assert(kYounger >= 0 && 4 + kYounger <= 63, "vmcnt immediate");
+        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(4 + kYounger) : "memory");
 #endif
 #ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
@@ -268,6 +264,135 @@ __device__ __forceinline__ void layer_wide_v4(Pipe& pipe, f32x4 (&acc)[16], cons
         act[4 * t + 3] = bv[t].w;
     }
     layer_wide<KT>(pipe, acc, act, hook);
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-precision ("f16x3") pieces shared by the forward and the data-gradient kernels
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 q2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ h2 pack_rtz(float a, float b) {
+    return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// x - (float)pair[kHigh] in one instruction (v_fma_mix_f32 reads the f16 half directly; the compiler
+// itself only emits v_cvt_f32_f16 + v_sub_f32 for this).
+// Inline asm gets NONE of the wait states hipcc inserts around MFMAs (its hazard recognizer does not
+// look inside asm), so the instruction may only touch registers that a compiler-visible VALU
+// instruction wrote last (scripts/isa_hazards.py, rule R1): the result is tied to `x`'s register
+// ("+v": x itself if it dies here, else a v_mov copy — either way written by a visible VALU after
+// every MFMA that used the register), never a fresh temporary, which the allocator is free to take
+// from the accumulators of MFMAs still in flight.
+template <int kHigh>
+__device__ __forceinline__ float residual(float x, const h2& pair) {
+    float r = x;
+    if (kHigh)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
+    return r;
+}
+
+// (v | .) half of split8: one register tile -> its four hi and four lo halfs
+__device__ __forceinline__ void split4(const f32x4& v, h2& hi0, h2& hi1, h2& lo0, h2& lo1) {
+    hi0 = pack_rtz(v.x, v.y);
+    hi1 = pack_rtz(v.z, v.w);
+#ifdef NERF_ABL_SPLIT        /* timing experiment only */
+    lo0 = hi0;
+    lo1 = hi1;
+    return;
+#endif
+    lo0 = pack_rtz(residual<0>(v.x, hi0), residual<1>(v.y, hi0));
+    lo1 = pack_rtz(residual<0>(v.z, hi1), residual<1>(v.w, hi1));
+}
+__device__ __forceinline__ h8 join8(const h2& a, const h2& b, const h2& c, const h2& d) {
+    return h8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+
+// (v0 | v1) -> hi, lo with hi + lo = v to ~22 bits.  Round-toward-zero never overflows to inf.
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, h8& hi, h8& lo) {
+    h2 nh[4], nl[4];
+    split4(v0, nh[0], nh[1], nl[0], nl[1]);
+    split4(v1, nh[2], nh[3], nl[2], nl[3]);
+    hi = join8(nh[0], nh[1], nh[2], nh[3]);
+    lo = join8(nl[0], nl[1], nl[2], nl[3]);
+}
+
+// "1 MFMA, then `valu` VALU instructions", twice (the tail of a unit)
+template <int kValu>
+__device__ __forceinline__ void interleave_2() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);
+    }
+}
+
+// A-operand register sets of the unit pipeline: a unit = one (out tile, k block) pair = two
+// ds_read_b128 (hi slab, lo slab) and three MFMAs (48 cycles); the reads of unit U + kSets - 1 are
+// issued right after the first MFMA of unit U, so an LDS read has kSets - 1 units to land (the
+// compiler's counted lgkmcnt waits leave the younger reads in flight).  A stage's hand-over
+// (vmcnt wait, barrier, DMA issue) therefore sits kSets - 1 units before the stage's first MFMA;
+// at that barrier every wave has issued AND retired (lgkmcnt(0)) all reads of the stage it is
+// still computing on, whose slot the DMA issued next overwrites.
+constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unroller (dynamic register indexing)
+
+
+// The data gradient's split-precision layer: acc[T] += sum over KB k blocks of 32, B operands
+// already split into f16 pairs (bhi / blo: block m = the caller's register tiles 2m, 2m + 1).
+// Image and stage order as in the forward's layer_fused_h: stage (half, m) holds out tiles
+// 8 half .. 8 half + 7 of k block m as {hi slab, lo slab} pairs; same unit pipeline (kSets operand
+// sets, hand-over kSets - 1 units ahead).  hook(t) runs once per stage right after its hand-over.
+// kEntryYounger: vector-memory operations the caller is KNOWN to have issued after the DMA of this
+// layer's stage 1 (saves of the LayerNorm backward, prefetches of the next x_hat tile): stages 0 and
+// 1 were issued before them, so their counted waits leave those operations in flight.
+template <int KB, int kEntryYounger, class Pipe, class Hook = NoHook>
+__device__ __forceinline__ void layer_wide_h(Pipe& pipe, f32x4 (&acc)[16], const h8 (&bhi)[KB],
+                                             const h8 (&blo)[KB], Hook hook = Hook()) {
+    constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
+    h8 ah[kSets], al[kSets];
+    __builtin_amdgcn_s_setprio(0);
+    const h8* st = (const h8*)pipe.template open_stage<kEntryYounger>();
+#pragma unroll
+    for (int u = 0; u < kSets - 1; ++u) {
+        ah[u] = st[(2 * u) * 64];
+        al[u] = st[(2 * u + 1) * 64];
+    }
+    pipe.prefetch_next();
+    hook(0);
+#pragma unroll
+    for (int s = 0; s < kStages; ++s) {
+        const int half = s / KB, m = s % KB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int U = 8 * s + i, set = U % kSets;
+            const int T = 8 * half + i;
+            acc[T] = mfma_h(ah[set], bhi[m], acc[T]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (U + kSets - 1 < kUnits) {
+                const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
+                if (ip == 0) {
+                    if (s == 0) st = (const h8*)pipe.template open_stage<kEntryYounger>();
+                    else st = (const h8*)pipe.open_stage();
+                }
+                ah[pset] = st[(2 * ip) * 64];
+                al[pset] = st[(2 * ip + 1) * 64];
+                if (ip == 0) {
+                    pipe.prefetch_next();
+                    hook(s + 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[T] = mfma_h(ah[set], blo[m], acc[T]);
+            acc[T] = mfma_h(al[set], bhi[m], acc[T]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(2);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -65,7 +65,15 @@ constexpr int kWScaleLog2 = 8;
 constexpr int kXScaleLog2 = 4;
 constexpr int kHBlobOffset = kBwdBlobOffset + kBwdBlobFloats;
 constexpr int kHSmallOffset = kHBlobOffset + kBlobFloats;
-constexpr int kPackedFloats = kHSmallOffset + kSmallFloats;
+// Transposed split-precision image for the data gradient (dX = W^T dY on v_mfma_f32_16x16x32_f16):
+// the 68 stages of the transposed fp32 image in the slab format above.  A rows = IN features of the
+// forward layer (out tiles of the product), k = its OUT features in blocks m of 32:
+//   stages 0..3   : layer 5 (64 padded outs = 2 k blocks): stage s = half * 2 + m
+//   stages 4..67  : layers 4, 3, 2, 1, 16 stages each:     stage s = half * 8 + m
+//   pair i of a stage = in tile 8 * half + i; element (lane (row, kg), jj) of its slabs
+//   = 2^kWScaleLog2 * W[32 m + 16 (jj >> 2) + 4 kg + (jj & 3)][16 (8 half + i) + row]
+constexpr int kBwdHBlobOffset = kHSmallOffset + kSmallFloats;
+constexpr int kPackedFloats = kBwdHBlobOffset + kBwdBlobFloats;
 
 // flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts
 constexpr int kGradElements = kHidden * kEncIn + kHidden + 2 * kHidden

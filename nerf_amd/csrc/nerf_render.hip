@@ -314,78 +314,6 @@ typedef Moments HMoments;
 #else
 typedef MomentsPk HMoments;
 #endif
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef __fp16 q2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x4 mfma_h(const h8& a, const h8& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ h2 pack_rtz(float a, float b) {
-    return __builtin_bit_cast(h2, (q2)__builtin_amdgcn_cvt_pkrtz(a, b));
-}
-// x - (float)pair[kHigh] in one instruction (v_fma_mix_f32 reads the f16 half directly; the compiler
-// itself only emits v_cvt_f32_f16 + v_sub_f32 for this).
-// Inline asm gets NONE of the wait states hipcc inserts around MFMAs (its hazard recognizer does not
-// look inside asm), so the instruction may only touch registers that a compiler-visible VALU
-// instruction wrote last (scripts/isa_hazards.py, rule R1): the result is tied to `x`'s register
-// ("+v": x itself if it dies here, else a v_mov copy — either way written by a visible VALU after
-// every MFMA that used the register), never a fresh temporary, which the allocator is free to take
-// from the accumulators of MFMAs still in flight.
-template <int kHigh>
-__device__ __forceinline__ float residual(float x, const h2& pair) {
-    float r = x;
-    if (kHigh)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
-    else
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pair));
-    return r;
-}
-
-// (v | .) half of split8: one register tile -> its four hi and four lo halfs
-__device__ __forceinline__ void split4(const f32x4& v, h2& hi0, h2& hi1, h2& lo0, h2& lo1) {
-    hi0 = pack_rtz(v.x, v.y);
-    hi1 = pack_rtz(v.z, v.w);
-#ifdef NERF_ABL_SPLIT        /* timing experiment only */
-    lo0 = hi0;
-    lo1 = hi1;
-    return;
-#endif
-    lo0 = pack_rtz(residual<0>(v.x, hi0), residual<1>(v.y, hi0));
-    lo1 = pack_rtz(residual<0>(v.z, hi1), residual<1>(v.w, hi1));
-}
-__device__ __forceinline__ h8 join8(const h2& a, const h2& b, const h2& c, const h2& d) {
-    return h8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-}
-
-// (v0 | v1) -> hi, lo with hi + lo = v to ~22 bits.  Round-toward-zero never overflows to inf.
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, h8& hi, h8& lo) {
-    h2 nh[4], nl[4];
-    split4(v0, nh[0], nh[1], nl[0], nl[1]);
-    split4(v1, nh[2], nh[3], nl[2], nl[3]);
-    hi = join8(nh[0], nh[1], nh[2], nh[3]);
-    lo = join8(nl[0], nl[1], nl[2], nl[3]);
-}
-
-// "1 MFMA, then `valu` VALU instructions", twice (the tail of a unit)
-template <int kValu>
-__device__ __forceinline__ void interleave_2() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);
-    }
-}
-
-// A-operand register sets of the unit pipeline: a unit = one (out tile, k block) pair = two
-// ds_read_b128 (hi slab, lo slab) and three MFMAs (48 cycles); the reads of unit U + kSets - 1 are
-// issued right after the first MFMA of unit U, so an LDS read has kSets - 1 units to land (the
-// compiler's counted lgkmcnt waits leave the younger reads in flight).  A stage's hand-over
-// (vmcnt wait, barrier, DMA issue) therefore sits kSets - 1 units before the stage's first MFMA;
-// at that barrier every wave has issued AND retired (lgkmcnt(0)) all reads of the stage it is
-// still computing on, whose slot the DMA issued next overwrites.
-constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unroller (dynamic register indexing)
-
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
 // built (normalise tile by tile, then split) during stage (0, m).
@@ -827,6 +755,38 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int out = 16 * T + row;
             if (out < kOut) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
         }
+    } else if (e >= kBwdHBlobOffset) {
+        // transposed split-precision image (nerf_layout.h): two f16 of one slab per float slot
+        const int eb = e - kBwdHBlobOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k;
+            float w = 0.f;
+            if (stage < kStagesL5) {
+                const int half = stage / 2, m = stage % 2;
+                const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
+                if (out < kOut) w = pa.p[20][out * kHidden + 16 * (8 * half + pair) + row];
+            } else {
+                const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
+                const int s = (stage - kStagesL5) % kStagesHidden;
+                const int half = s / 8, m = s % 8;
+                const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
+                w = pa.p[4 * L][out * kHidden + 16 * (8 * half + pair) + row];
+            }
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;              // round to nearest
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
     } else if (e >= kHSmallOffset) {
         // small image of the split-precision path: bias * 2^12, gamma * 2^4, beta * 2^4
         const int i = e - kHSmallOffset;

@@ -291,8 +291,10 @@ class NeRF(nn.Module):
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
                    cameras=None, ray_begin=0, t_values=None, u=None, noise=None,
                    density_noise_std=0.0, rng_mode=0, rng_state=None, packed=None, rgb=None, seg=None,
-                   mean=None, cov=None, raw=None, weights=None, train_workspace=None, out_t=None):
-        """Fill a NerfHipRenderArgs block (include/nerf_hip.h) from tensors."""
+                   mean=None, cov=None, raw=None, weights=None, train_workspace=None, out_t=None,
+                   precision=None):
+        """Fill a NerfHipRenderArgs block (include/nerf_hip.h) from tensors.  ``precision``: the
+        backward passes the arithmetic its forward ran with (already range-checked)."""
         args.rays_o, args.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
         if cameras is not None:
             cam_o, cam_r, image_h, image_w, focal = cameras
@@ -313,6 +315,9 @@ class NeRF(nn.Module):
         args.out_mean, args.out_cov, args.out_t = _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(out_t)
         args.out_raw, args.out_weights = _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
+        if precision is not None:
+            args.precision = precision
+            return
         which = self.precision if train_workspace is None else self.train_precision
         if which not in _lib.PRECISIONS:
             raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {which!r}")

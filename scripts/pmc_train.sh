@@ -17,6 +17,6 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 summ() { python3 scripts/pmc_summary.py $OUT/${TAG}_a $OUT/${TAG}_d $OUT/${TAG}_b $OUT/${TAG}_fetch $OUT/${TAG}_write --kernel "$2" > $OUT/${TAG}_$1_pmc.json; }
 summ fwd "nerf_render_fwd_kernel<true"
-summ dgrad nerf_bwd_data_kernel
+summ dgrad nerf_bwd_data_
 summ wgrad nerf_wgrad_kernel
 grep -h "nerf_\|Name" $OUT/${TAG}_trace/*kernel_stats.csv | head -12
