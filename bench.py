@@ -133,10 +133,10 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
-            "arithmetic": ("training forward on f16 triples (three f16 MFMAs per product), "
-                           if train_precision == "f16x3" else "training forward on fp32 MFMA, ")
-                          + "data gradient on fp32 MFMA, weight gradient on bf16 triples (six bf16 MFMAs per "
-                            "product); fp32 accumulate everywhere"}
+            "arithmetic": ("training forward and data gradient on f16 pairs (three f16 MFMAs per product), "
+                           if train_precision == "f16x3" else "training forward and data gradient on fp32 MFMA, ")
+                          + "weight gradient on bf16 triples (six bf16 MFMAs per product); fp32 accumulate "
+                            "everywhere"}
 
 
 def legacy_workload_timing(dev, steps=3, warmup=1):
@@ -369,7 +369,7 @@ def main():
                 "roofline": roofline(other, o["rays_per_rank"], o["kernel_ms"], o["launches"], True),
             }
             line["train_step"] = train_step_timing(dev)
-            line["train_step_f16x3_forward"] = train_step_timing(dev, train_precision="f16x3")
+            line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
             line["legacy_network"] = legacy_workload_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
