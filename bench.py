@@ -110,7 +110,7 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     torch.manual_seed(0)
     model = NeRF().to(dev)
     model.train_precision = train_precision
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)      # as nerf_amd/trainer.py
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)
 

@@ -38,7 +38,7 @@ class RenderRaysFunction(torch.autograd.Function):
                     t_values)
         ctx.workspace = workspace
         ctx.precision = _lib.PRECISIONS[model.train_precision]   # the data gradient uses the same arithmetic
-        ctx.packed = model.packed_parameters()      # the image this forward used
+        ctx.packed = model._last_packed             # the image this forward used (its own buffer)
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(rgb, seg)
         ctx.mark_non_differentiable(weights)

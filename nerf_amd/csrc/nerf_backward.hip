@@ -15,6 +15,8 @@
 //      = column sums of dY).
 //   3. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
 //      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
+#include <type_traits>
+
 #include "nerf_device.h"
 
 using namespace nerf_layout;
@@ -42,6 +44,8 @@ struct BwdArgs {
     int64_t groups;
     TrainLayout L;
     float* gb_partial;          // [grid][5][2][256]
+    float* dymax;               // [grid][8]: largest |dY| each data-gradient workgroup saw, per layer
+                                // (0..4: dy[L], 5: dL/d(out)); split-precision path only
     float* slabs;               // [splits][kSlabFloats]
     float* grad;
     int32_t splits, data_grid;
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs b
 // so the scale is undone on the accumulators; f16 keeps 11 bits per half down to 2^-14, i.e. an
 // element 2^-16 of the row's largest still has all 22 bits).  Returns the scale; `unscale` also
 // removes the weights' 2^kWScaleLog2.
-__device__ __forceinline__ float row_scale(float amax_lane, float& unscale) {
-    const float amax = group_max(amax_lane);
+__device__ __forceinline__ float row_scale(float amax_lane, float& unscale, float& amax) {
+    amax = group_max(amax_lane);
     uint32_t e = __builtin_bit_cast(uint32_t, amax) >> 23;            // amax >= 0
     e = e < 32u ? 32u : e;                                            // rows below 2^-95: treated as 2^-95
     unscale = __builtin_bit_cast(float, (e - 12u - (uint32_t)kWScaleLog2) << 23);
@@ -285,6 +289,14 @@ __device__ __forceinline__ float abs_max4(float m, const f32x4& v) {
 
 // Stage hook of the split-precision loops: only the wave-ordered gamma/beta adds (the x_hat
 // prefetch is issued before the loop: a 0.2 us stage cannot hide an HBM load behind one hand-over).
+// The weight-gradient kernel's f16-pair form needs ONE scale per layer for the whole batch: every
+// wave folds its samples' maxima into an LDS word of its workgroup (integer max on the bits of a
+// non-negative float: order-independent, so still bitwise reproducible).
+__device__ __forceinline__ void note_max(int* word, float amax, int lane) {
+    const float w = row_max(amax);                // lanes 0..15 = the wave's 16 samples
+    if (lane == 0) atomicMax(word, __builtin_bit_cast(int, w));
+}
+
 struct TurnHook {
     GammaBetaTurn& turn;
     __device__ __forceinline__ void operator()(int t) const { turn(t); }
@@ -396,10 +408,12 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     const int j = lane & 15, g = lane >> 4;
     float* const ws = a.train_workspace;
     float* const gb = (float*)(smem + kRingBytes + kSmallLdsBytes);
+    int* const wmax = (int*)(smem + kBwdLdsBytes);
 
     {
         stage_small_image(a.packed + kBlobFloats, (float*)(smem + kRingBytes));
         for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+        if (threadIdx.x < 8) wmax[threadIdx.x] = 0;
     }
     const float* small = (const float*)(smem + kRingBytes);
 
@@ -447,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                 float m = 0.f;
 #pragma unroll
                 for (int T = 0; T < 4; ++T) m = abs_max4(m, dout[T]);
-                const float sc = row_scale(m, unscale);
+                float amax;
+                const float sc = row_scale(m, unscale, amax);
+                note_max(wmax + 5, amax, lane);
                 h8 bh[2], bl[2];
                 split8(dout[0] * sc, dout[1] * sc, bh[0], bl[0]);
                 split8(dout[2] * sc, dout[3] * sc, bh[1], bl[1]);
@@ -467,18 +483,22 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                                           ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
                                           turn, unscale);
 #endif
-                if (L == 0) break;
+                if (L == 0) break;                // dy[0] feeds only the weight gradient
                 // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
                 // all of them younger than the two stages this layer's loop opens first
                 const float* xrow_n = ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g;
 #pragma unroll
                 for (int T = 0; T < 16; ++T) xh[T] = BWD_XHAT(xrow_n + T * 16);
                 rstd = ws[ba.L.rstd[L - 1] + sp];
+                // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
+                // workgroup's maximum) the weight-gradient kernel's
                 float m = 0.f;
 #pragma unroll
                 for (int T = 0; T < 16; ++T)
                     m = abs_max4(m, f32x4{act[4 * T], act[4 * T + 1], act[4 * T + 2], act[4 * T + 3]});
-                const float sc = row_scale(m, unscale);
+                float amax;
+                const float sc = row_scale(m, unscale, amax);
+                note_max(wmax + L, amax, lane);
                 h8 bh[8], bl[8];
 #pragma unroll
                 for (int mb = 0; mb < 8; ++mb) {
@@ -500,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     __syncthreads();
     for (int i = threadIdx.x; i < kGbFloats; i += 256)
         ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+    if (threadIdx.x < 8) ba.dymax[(int64_t)blockIdx.x * 8 + threadIdx.x] = __builtin_bit_cast(float, wmax[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -914,10 +935,386 @@ __device__ __forceinline__ void wgrad_body_bf16(const BwdArgs& ba, char* smem, c
     }
 }
 
-#ifdef NERF_WGRAD_FP32       /* the exact-fp32 32x32x2 GEMM (kept as the comparison build) */
-#define WGRAD_BODY wgrad_body
+// ---------------------------------------------------------------------------------------------
+// The bf16-triple GEMM as ONE continuous stream of 16-sample k-steps over a 4-slot LDS ring
+// (round 2; the 32-sample double-buffered form above is kept behind -DNERF_WGRAD_TILE32).
+// Why: with one wave per SIMD nothing hides a tile hand-over.  The two-buffer form exposed, per
+// 32-sample tile, the conversion of the tile's first operands (5 operands x 8 values x ~7 VALU)
+// and a vmcnt(0) that waited for a tile whose DMA had been issued only half a tile earlier; the
+// matrix pipe was ~50 % busy.  Here
+//   * a ring slot holds ONE k-step (16 samples: [16][OutW] dY then [16][InW] X);
+//   * during step t the VALU converts A(t, a + 1) from slot t and, for step t + 1, A(t + 1, 0) and
+//     all B operands from slot t + 1, so no conversion is ever exposed after the prologue;
+//   * the DMA of step t + 3 is issued during step t into the slot step t - 1 just vacated, i.e. it
+//     has two whole steps to land; the hand-over at the end of step t waits only for this wave's
+//     pieces of step t + 2 (counted vmcnt: the pieces of step t + 3 stay in flight), then one
+//     barrier makes every wave's pieces visible and proves every wave has left step t
+//     (write-after-read safety of the slot that step t + 4's DMA takes next).
+// The DMA is issued from inline asm (as in WeightPipe::issue): with the builtin the compiler's
+// wait-count pass would put a vmcnt(0) in front of every LDS read.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingStep = 16;                    // samples per ring slot = one MFMA k-step
+constexpr int kRingSlots = 4;
+constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 KiB (hidden shape)
+static_assert(kRingSlots * kRingSlotBytes == 2 * ShapeHid::kTileBytes, "same LDS as the two-buffer form");
+
+// N (<= 4) consecutive 1 KiB pieces: global (uniform base + lane * 16 + k KiB) -> LDS (base + k KiB)
+template <int N>
+__device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
+    static_assert(N >= 1 && N <= 4, "immediate offsets reach 3 KiB");
+    const uint64_t base_u = (uint64_t)(uintptr_t)src;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+    const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+    const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+    uint32_t m0_saved;
+#ifndef NERF_EXP_WGRAD_NODMA     /* timing experiment only */
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 2\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        ".if %c4 > 1\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t.endif\n\t"
+        ".if %c4 > 2\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\t.endif\n\t"
+        ".if %c4 > 3\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t.endif\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(m0_saved)
+        : "v"(lane * 16), "s"(d), "s"(sbase), "n"(N)
+        : "memory");
+#endif
+}
+
+// DMA instructions every wave issues per k-step (the same count on every wave: the hand-over's
+// vmcnt is an immediate).  dY rows are kOutW floats, X rows kInW: both regions are contiguous.
+template <class Sh>
+struct RingPlan {
+    static constexpr int kDyPieces = kRingStep * Sh::kOutW * 4 / 1024;    // 16 / 16 / 4
+    static constexpr int kXPieces = kRingStep * Sh::kInW * 4 / 1024;      // 6 / 16 / 16
+    static constexpr int kDyPerWave = (kDyPieces + 3) / 4, kXPerWave = (kXPieces + 3) / 4;
+    static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
+    static constexpr int kXOffset = kRingStep * Sh::kOutW * 4;            // X behind dY in the slot
+};
+
+// part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
+// past the region re-fetches the region's last pieces instead (same bytes to the same place).
+template <class Sh, int kPart>
+__device__ __forceinline__ void ring_issue_part(const float* dy, const float* x, int64_t sample0, char* slot,
+                                                int wave, int lane) {
+    typedef RingPlan<Sh> P;
+    constexpr int total = kPart == 0 ? P::kDyPieces : P::kXPieces;
+    constexpr int per = kPart == 0 ? P::kDyPerWave : P::kXPerWave;
+    int first = wave * per;
+    if (first + per > total) first = total - per;
+    const char* src = kPart == 0 ? (const char*)(dy + sample0 * Sh::kOutW) : (const char*)(x + sample0 * Sh::kInW);
+    char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
+    ring_dma<per>(src + first * 1024, dst + first * 1024, lane);
+}
+
+struct H2 {                   // an operand as f16 pairs: value = (h + l) / scale
+    h8 h, l;
+};
+__device__ __forceinline__ f32x16 mfma_hw(const h8& a, const h8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// kF16 (the split-precision training mode): operands as f16 PAIRS instead of bf16 triples — three
+// v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, and 4 instead of ~7 VALU per value.
+// X = relu(gamma x_hat + beta) (or the encoded inputs) is O(1) and enters times 2^4 as in the
+// forward; dY enters times ONE power of two per layer and launch, chosen from the largest |dY| of
+// the whole batch (`dymax`, written by the data-gradient kernel) so that it lands in [2^12, 2^13):
+// a sample's row cannot have its own scale here because the product sums over samples.  Elements
+// more than 2^16 below the batch maximum lose relative precision, but never more than 2^-38 of that
+// maximum absolutely — below fp32 rounding of any sum the large elements take part in.  (The bf16
+// form needs no scale: bf16 has fp32's exponent range; it stays the fp32 training mode's arithmetic.)
+template <class Sh, bool kAffine, bool kF16 = false>
+__device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, const float* dy, const float* x,
+                                                const float* small_prev, int w_off, int b_off, int split,
+                                                int max_index = 0) {
+    typedef RingPlan<Sh> P;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int out0, in0;                                // first 32-wide tile of this wave
+    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
+    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
+    else { out0 = 0; in0 = 2 * wave; }
+
+    float ga[Sh::kTi], be[Sh::kTi];
+#pragma unroll
+    for (int b = 0; b < Sh::kTi; ++b) {
+        const int f = 32 * (in0 + b) + (lane & 31);
+        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
+        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
+        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
+        if (kF16) {                               // X enters the MFMAs times 2^kXScaleLog2
+            ga[b] *= (float)(1 << kXScaleLog2);
+            be[b] *= (float)(1 << kXScaleLog2);
+        }
+    }
+    float a_scale = 1.0f, un_scale = 1.0f;        // dY scale and what divides it (and X's) out again
+    if (kF16) {
+        float m = 0.f;
+        for (int q = threadIdx.x; q < ba.data_grid; q += 256) m = __builtin_fmaxf(m, ba.dymax[(int64_t)q * 8 + max_index]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+        float* red = (float*)smem;
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+        __syncthreads();                          // the ring's DMA may overwrite `red` from here on
+        uint32_t e = __builtin_bit_cast(uint32_t, m) >> 23;
+        e = e < 32u ? 32u : e;
+        a_scale = __builtin_bit_cast(float, (266u - e) << 23);                      // 2^(12 - (e - 127))
+        un_scale = __builtin_bit_cast(float, (e - 12u - (uint32_t)kXScaleLog2) << 23);
+    }
+
+    f32x16 acc[Sh::kTo][Sh::kTi];
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[Sh::kTo];
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a) bsum[a] = 0.f;
+
+    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
+    int64_t tile_end = tile_begin + ba.tiles_per_split;
+    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
+    const int64_t n_steps = tile_end > tile_begin ? 2 * (tile_end - tile_begin) : 0;   // even
+    const int64_t sample_begin = tile_begin * kKs;
+    const int i = lane & 31, kk = lane >> 5;
+
+    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * kRingSlotBytes; };
+    auto issue_step = [&](int64_t t) {            // all pieces of step t (prologue)
+        ring_issue_part<Sh, 0>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
+        ring_issue_part<Sh, 1>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
+    };
+    auto b_value = [&](float raw, int b) {
+        return kAffine ? __builtin_fmaxf(__builtin_fmaf(raw, ga[b], be[b]), 0.f) : (kF16 ? raw * ga[b] : raw);
+    };
+
+    constexpr int kBPerSlot = (Sh::kTi + Sh::kTo - 1) / Sh::kTo;
+    constexpr int kPerProduct = kF16 ? 3 : 6;
+    constexpr int kMfmas = kPerProduct * Sh::kTi;             // per slot
+    constexpr int kLead = kMfmas / 6;
+    // conversion work items per operand — bf16: 8 values + 2 packing items; f16: 4 value pairs
+    // (scale / affine) + 4 pair splits (hi = pkrtz, two residuals, lo = pkrtz)
+    constexpr int kItemsPerOp = kF16 ? 8 : 10;
+    constexpr int kItems = kItemsPerOp * (1 + kBPerSlot);
+    typedef typename std::conditional<kF16, H2, Bf3>::type Operand;
+    static_assert(Sh::kTo % 2 == 0, "the A operand sets ping-pong slot by slot");
+
+    // One k-step: MFMAs on (at[0] of slot 0, bcur) while the VALU builds the next A operands and bnext.
+    // at[2]: A operand sets, slot a uses at[a & 1] and converts into at[(a & 1) ^ 1].
+    Operand at[2];
+    auto k_step = [&](int64_t t, Operand (&bcur)[Sh::kTi], Operand (&bnext)[Sh::kTi]) {
+        const float* dyt = (const float*)slot_of(t);
+        const float* dyn = (const float*)slot_of(t + 1);
+        const float* xn = (const float*)(slot_of(t + 1) + P::kXOffset);
+        const bool has_next = t + 1 < n_steps;    // else the conversions chew on stale bytes, unused
+        const bool issue_more = t + 3 < n_steps;
+        char* fill = slot_of(t + 3);
+#pragma unroll
+        for (int a = 0; a < Sh::kTo; ++a) {
+            // the DMA of step t + 3: dY pieces behind the first slot's first MFMA, X pieces behind the second's
+            const int na = a + 1 < Sh::kTo ? a + 1 : 0;
+            const float* asrc = a + 1 < Sh::kTo ? dyt : dyn;
+            float raw[1 + kBPerSlot][8];
+#ifdef NERF_EXP_WGRAD_NOLDS      /* timing experiment only: operands are not read */
+#pragma unroll
+            for (int q = 0; q < 1 + kBPerSlot; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) raw[q][jj] = ga[0] * (float)(jj + q);
 #else
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc[(8 * kk + jj) * Sh::kOutW + 32 * (out0 + na) + i];
+#pragma unroll
+            for (int q = 0; q < kBPerSlot; ++q) {
+                const int b = a * kBPerSlot + q;
+                if (b < Sh::kTi) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[(8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
+                }
+            }
+#endif
+            unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
+            u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
+            h2 qh[1 + kBPerSlot][4], ql[1 + kBPerSlot][4];   // f16 form: pair p of the operand, hi / lo
+            const Operand& ac = at[a & 1];
+            Operand& an = at[(a & 1) ^ 1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < kMfmas; ++m) {
+                const int b = m / kPerProduct, tt = m % kPerProduct;
+                if constexpr (kF16) {
+                    acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
+                } else {
+                    const bf8& ta = tt == 5 ? ac.l : (tt == 2 || tt == 3 ? ac.m : ac.h);
+                    const bf8& tb = tt == 4 ? bcur[b].l : (tt == 1 || tt == 3 ? bcur[b].m : bcur[b].h);
+                    acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 0 && a < 2 && issue_more) {
+                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
+                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
+                }
+#pragma unroll
+                for (int it = 0; it < kItems; ++it) {
+                    if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
+                    const int op = it / kItemsPerOp, w = it % kItemsPerOp;   // op 0: next A operand, 1..: B operands of step t + 1
+                    const int bq = a * kBPerSlot + (op - 1);
+                    if (op > 0 && bq >= Sh::kTi) continue;
+                    if constexpr (kF16) {
+                        if (w < 4) {                  // values 2w, 2w + 1: scale (dY) or affine + ReLU (X)
+#pragma unroll
+                            for (int e2 = 0; e2 < 2; ++e2) {
+                                float val = raw[op][2 * w + e2];
+                                asm volatile("" : "+v"(val));
+                                if (op > 0) val = b_value(val, bq);
+                                else {
+                                    val *= a_scale;
+                                    bsum[na] += (a + 1 < Sh::kTo || has_next) ? val : 0.f;
+                                }
+                                asm volatile("" : "+v"(val));
+                                raw[op][2 * w + e2] = val;
+                            }
+                        } else {                      // pair w - 4: hi = pkrtz, residuals, lo = pkrtz
+                            const int pp = w - 4;
+                            const float v0 = raw[op][2 * pp], v1 = raw[op][2 * pp + 1];
+                            qh[op][pp] = pack_rtz(v0, v1);
+                            ql[op][pp] = pack_rtz(residual<0>(v0, qh[op][pp]), residual<1>(v1, qh[op][pp]));
+                            asm volatile("" : "+v"(ql[op][pp]));
+                            if (pp == 3) {
+                                Operand r;
+                                r.h = join8(qh[op][0], qh[op][1], qh[op][2], qh[op][3]);
+                                r.l = join8(ql[op][0], ql[op][1], ql[op][2], ql[op][3]);
+                                if (op == 0) an = r;
+                                else bnext[bq] = r;
+                            }
+                        }
+                    } else {
+#ifdef NERF_EXP_WGRAD_NOCONV     /* timing experiment only: raw bits instead of the bf16 triple */
+                    if (w < 8) {
+                        th[op][w] = tm[op][w] = tl[op][w] = __builtin_bit_cast(unsigned, raw[op][w]);
+                        continue;
+                    }
+#endif
+                    if (w < 8) {
+                        float val = raw[op][w];
+                        asm volatile("" : "+v"(val));
+                        if (op > 0) val = b_value(val, bq);
+                        // bias gradient: every dY value of the wave's out tiles is converted exactly once
+                        if (op == 0) bsum[na] += (a + 1 < Sh::kTo || has_next) ? val : 0.f;
+                        th[op][w] = __builtin_bit_cast(unsigned, val) & 0xffff0000u;
+                        const float r1 = val - __builtin_bit_cast(float, th[op][w]);
+                        tm[op][w] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+                        tl[op][w] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, tm[op][w]));
+                        asm volatile("" : "+v"(tl[op][w]));
+                    } else {
+#pragma unroll
+                        for (int pp = 2 * (w - 8); pp < 2 * (w - 8) + 2; ++pp) {
+                            unsigned lo_h = th[op][2 * pp], lo_m = tm[op][2 * pp], lo_l = tl[op][2 * pp];
+                            asm volatile("" : "+v"(lo_h), "+v"(lo_m), "+v"(lo_l));
+                            ph[op][pp] = __builtin_amdgcn_perm(th[op][2 * pp + 1], lo_h, 0x07060302u);
+                            pm[op][pp] = __builtin_amdgcn_perm(tm[op][2 * pp + 1], lo_m, 0x07060302u);
+                            pl[op][pp] = __builtin_amdgcn_perm(tl[op][2 * pp + 1], lo_l, 0x07060302u);
+                            asm volatile("" : "+v"(ph[op][pp]), "+v"(pm[op][pp]), "+v"(pl[op][pp]));
+                        }
+                        if (w == 9) {
+                            Bf3 r;
+                            r.h = __builtin_bit_cast(bf8, ph[op]);
+                            r.m = __builtin_bit_cast(bf8, pm[op]);
+                            r.l = __builtin_bit_cast(bf8, pl[op]);
+                            if (op == 0) an = r;
+                            else bnext[bq] = r;
+                        }
+                    }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // hand-over: this wave's pieces of step t + 2 have landed (the kPerWave pieces of step t + 3,
+        // issued above, may still fly), its LDS reads are done; behind the barrier every wave's are
+        if (issue_more) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(P::kPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    if (n_steps > 0) {
+        // prologue: three steps in flight, the first two landed; step 0's operands converted up front
+        issue_step(0);
+        issue_step(1);
+        if (n_steps > 2) {
+            issue_step(2);
+            asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(P::kPerWave) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        Operand b0[Sh::kTi], b1[Sh::kTi];
+        auto convert = [&](const float (&v)[8]) {
+            if constexpr (kF16) {
+                Operand r;
+                split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, r.h, r.l);
+                return r;
+            } else {
+                return split_bf3(v);
+            }
+        };
+        {
+            const float* dyt = (const float*)slot_of(0);
+            const float* xt = (const float*)(slot_of(0) + P::kXOffset);
+#pragma unroll
+            for (int b = 0; b < Sh::kTi; ++b) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = b_value(xt[(8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i], b);
+                b0[b] = convert(v);
+            }
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                v[jj] = dyt[(8 * kk + jj) * Sh::kOutW + 32 * out0 + i] * a_scale;
+                bsum[0] += v[jj];
+            }
+            at[0] = convert(v);
+        }
+        for (int64_t t = 0; t < n_steps; t += 2) {    // two steps per trip: the B sets swap roles
+            k_step(t, b0, b1);
+            k_step(t + 1, b1, b0);
+        }
+    }
+
+    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a)
+#pragma unroll
+        for (int b = 0; b < Sh::kTi; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r] * un_scale;
+            }
+    const float un_bias = kF16 ? un_scale * (float)(1 << kXScaleLog2) : 1.0f;      // the bias sums carry dY's scale only
+#pragma unroll
+    for (int a = 0; a < Sh::kTo; ++a) {
+        const float both = bsum[a] + __shfl_xor(bsum[a], 32);       // the two 8-sample halves of a k-step
+        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both * un_bias;
+    }
+}
+
+#if defined(NERF_WGRAD_FP32)    /* the exact-fp32 32x32x2 GEMM (kept as the comparison build) */
+#define WGRAD_BODY wgrad_body
+#elif defined(NERF_WGRAD_TILE32) /* bf16 triples, 32-sample tiles in two buffers (round-1 form) */
 #define WGRAD_BODY wgrad_body_bf16
+#else
+#define WGRAD_BODY wgrad_body_ring
 #endif
 
 // All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
@@ -940,6 +1337,28 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     }
 }
 
+// The same launch in the split-precision training mode (f16-pair operands, see wgrad_body_ring).
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kBlobFloats;
+    if (job < 4) {
+        wgrad_body_ring<ShapeHid, true, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+                                              ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
+                                              small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
+                                              kSlabB + (job + 1) * kHidden, split, job + 1);
+    } else if (job == 4) {
+        // layer 0 (the smallest job) stays on bf16 triples: recording the batch maximum of dy[0] in the
+        // data-gradient kernel costs that kernel 250-700 B of spills per lane, whichever way it is written
+        wgrad_body_ring<ShapeL0, false, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB,
+                                               split);
+    } else {
+        wgrad_body_ring<ShapeL5, true, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                             kSlabW5, kSlabB + 5 * kHidden, split, 5);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // deterministic reduction of the partials into the flat gradient vector
 // ---------------------------------------------------------------------------------------------
@@ -951,26 +1370,37 @@ __device__ __forceinline__ int layer0_kernel_column(int feature) {
     return 16 * (q / 4) + 4 * g + (q % 4);
 }
 
-// sum of p[0], p[stride], ... (n terms) in a fixed association: four interleaved partial sums
-// (independent loads in flight), combined pairwise
+// sum of p[0], p[stride], ... (n terms) in a fixed association: sixteen interleaved partial sums,
+// combined pairwise — sixteen independent loads in flight per round trip (the loop is latency-bound:
+// with four, a 128-slab reduction was 32 dependent trips to HBM, 74 us for 156 MB)
 __device__ __forceinline__ float strided_sum(const float* p, int n, int64_t stride) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     int i = 0;
-    for (; i + 4 <= n; i += 4) {
-        s0 += p[(int64_t)i * stride];
-        s1 += p[(int64_t)(i + 1) * stride];
-        s2 += p[(int64_t)(i + 2) * stride];
-        s3 += p[(int64_t)(i + 3) * stride];
+    for (; i + 16 <= n; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p[(int64_t)(i + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += v[q];
     }
-    for (; i < n; ++i) s0 += p[(int64_t)i * stride];
-    return (s0 + s1) + (s2 + s3);
+    for (; i < n; ++i) acc[0] += p[(int64_t)i * stride];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int q = 0; q < w; ++q) acc[q] += acc[q + w];
+    return acc[0];
 }
 
-__global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kGradElements) return;
-    // locate e: tensor index in state_dict order
-    int tensor = 0, off = 0;
+constexpr int kReduceThreads = 256;
+constexpr int kReduceDirectBlocks = (kGradElements + kReduceThreads - 1) / kReduceThreads;
+constexpr int kGbElements = 5 * 2 * kHidden;                       // gamma / beta gradients
+constexpr int kReduceGbBlocks = kGbElements / 4;                   // one wave per element
+
+__device__ __forceinline__ void locate(int e, int& tensor, int& idx) {
+    tensor = 0;
+    int off = 0;
     for (;;) {
         const int L = tensor / 4, which = tensor % 4;
         const int n = which == 0 ? (L == 0 ? kHidden * kEncIn : (L == 5 ? kOut * kHidden : kHidden * kHidden))
@@ -979,23 +1409,41 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
         off += n;
         ++tensor;
     }
-    const int idx = e - off, L = tensor / 4, which = tensor % 4;
-    float sum = 0.f;
-    if (which >= 2) {                             // gamma (2) / beta (3): per-workgroup partials
-        const float* p = ba.gb_partial + L * 2 * kHidden + (which - 2) * kHidden + idx;
-        sum = strided_sum(p, ba.data_grid, kGbFloats);
-    } else {
-        int so;
-        if (which == 0) {
-            if (L == 0) so = kSlabW0 + (idx / kEncIn) * kEncIn + layer0_kernel_column(idx % kEncIn);
-            else if (L == 5) so = kSlabW5 + idx;
-            else so = kSlabWh + (L - 1) * kHidden * kHidden + idx;
-        } else {
-            so = kSlabB + L * kHidden + idx;
-        }
-        sum = strided_sum(ba.slabs + so, ba.splits, kSlabFloats);
+    idx = e - off;
+}
+
+// Blocks [0, kReduceDirectBlocks): one thread per gradient element that sums the weight-gradient
+// slabs (up to 128 terms).  Blocks behind them: the gamma / beta gradients, whose partials come one
+// per data-gradient WORKGROUP (up to 1,024 terms): one wave per element, lane l sums partials
+// l, l + 64, ... and the lanes combine in a fixed butterfly — still one fixed association.
+__global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
+    if ((int)blockIdx.x >= kReduceDirectBlocks) {
+        const int lane = threadIdx.x & 63;
+        const int ge = ((int)blockIdx.x - kReduceDirectBlocks) * 4 + (threadIdx.x >> 6);   // [layer][gamma|beta][256]
+        const int L = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
+        const float* p = ba.gb_partial + ge;
+        float sum = 0.f;
+        for (int q = lane; q < ba.data_grid; q += 64) sum += p[(int64_t)q * kGbFloats];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) ba.grad[grad_offset(4 * L + 2 + which) + idx] = sum;
+        return;
     }
-    ba.grad[e] = sum;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kGradElements) return;
+    int tensor, idx;
+    locate(e, tensor, idx);
+    const int L = tensor / 4, which = tensor % 4;
+    if (which >= 2) return;                       // gamma / beta: the blocks behind
+    int so;
+    if (which == 0) {
+        if (L == 0) so = kSlabW0 + (idx / kEncIn) * kEncIn + layer0_kernel_column(idx % kEncIn);
+        else if (L == 5) so = kSlabW5 + idx;
+        else so = kSlabWh + (L - 1) * kHidden * kHidden + idx;
+    } else {
+        so = kSlabB + L * kHidden + idx;
+    }
+    ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kSlabFloats);
 }
 
 int choose_splits(int64_t n_tiles) {
@@ -1011,7 +1459,7 @@ extern "C" {
 
 size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
     if (n_rays <= 0 || num_samples < 2) return 0;
-    return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * kGbFloats) * sizeof(float);
+    return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);
 }
 
 int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
@@ -1047,6 +1495,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
     ba.slabs = args->scratch;
     ba.gb_partial = args->scratch + (size_t)kMaxSplits * kSlabFloats;
+    ba.dymax = ba.gb_partial + (size_t)kMaxDataGrid * kGbFloats;
 
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
@@ -1057,13 +1506,17 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     static unsigned done_data = 0, done_wgrad = 0;
     const bool half = a.precision == NERF_HIP_PRECISION_F16X3;   // the arithmetic of the training forward
     static unsigned done_data_h = 0;
-    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_h_kernel, kBwdLdsBytes, device,
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_h_kernel, kBwdLdsBytes + 32, device,
                                                 &done_data_h)
               : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_kernel, kBwdLdsBytes, device,
                                                 &done_data);
     if (rc) return rc;
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_kernel, 2 * ShapeHid::kTileBytes, device,
                                          &done_wgrad);
+    if (rc) return rc;
+    static unsigned done_wgrad_h = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, 2 * ShapeHid::kTileBytes, device,
+                                         &done_wgrad_h);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ba.groups) grid = ba.groups;
@@ -1072,15 +1525,23 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
 
     hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                        dim3(256), 0, st, ba);
-    if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
     else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
 #ifdef NERF_EXP_WGRAD_HID_ONLY   /* timing experiment: hidden layers only (wrong gradients) */
-    hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 4), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+    const int wgrad_jobs = 4;
 #else
-    hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * 6), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+    const int wgrad_jobs = 6;
 #endif
-    const int threads = 256;
-    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((kGradElements + threads - 1) / threads), dim3(threads),
+#if defined(NERF_WGRAD_FP32) || defined(NERF_WGRAD_TILE32) || defined(NERF_WGRAD_BF16_ONLY)
+    const bool wgrad_half = false;
+#else
+    const bool wgrad_half = half;
+#endif
+    if (wgrad_half)
+        hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+    else
+        hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks), dim3(kReduceThreads),
                        0, st, ba);
     return nerf_common::check_hip(hipGetLastError(), "render_backward launch");
 }

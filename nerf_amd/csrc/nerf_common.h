@@ -153,6 +153,18 @@ inline const char* build_flags() {
 #ifdef NERF_WGRAD_FP32
            "NERF_WGRAD_FP32 "
 #endif
+#ifdef NERF_WGRAD_TILE32
+           "NERF_WGRAD_TILE32 "
+#endif
+#ifdef NERF_WGRAD_BF16_ONLY
+           "NERF_WGRAD_BF16_ONLY "
+#endif
+#ifdef NERF_EXP_WGRAD_NOLDS
+           "NERF_EXP_WGRAD_NOLDS "
+#endif
+#ifdef NERF_EXP_WGRAD_NOCONV
+           "NERF_EXP_WGRAD_NOCONV "
+#endif
 #ifdef NERF_STAGGER
            "NERF_STAGGER "
 #endif

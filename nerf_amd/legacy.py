@@ -73,21 +73,21 @@ class LegacyNeRF8x256(nn.Module):
         return order + [self.color.weight, self.color.bias]
 
     def packed_parameters(self):
+        """Re-packed on every call (one small launch), like nerf_amd.model.NeRF.packed_parameters:
+        version counters miss fused-optimiser and ``p.data`` updates."""
         params = self._param_list()
         dev = params[0].device
         for p in params:
             _require_device(p, "parameter")
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is None or self._packed_key != key or self._packed.device != dev:
-            lib = _lib.lib()
-            keep = [p.detach().contiguous() for p in params]
-            ptrs = (ctypes.c_void_p * _lib.NUM_LEGACY_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
-            packed = torch.empty(lib.nerf_hip_legacy_packed_bytes() // 4, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(lib.nerf_hip_legacy_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
-                           "nerf_hip_legacy_pack_weights")
-            self._packed, self._packed_key = packed, key
+        lib = _lib.lib()
+        keep = [p.detach().contiguous() for p in params]
+        ptrs = (ctypes.c_void_p * _lib.NUM_LEGACY_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
+        if self._packed is None or self._packed.device != dev:
+            self._packed = torch.empty(lib.nerf_hip_legacy_packed_bytes() // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.nerf_hip_legacy_pack_weights(ptrs, _lib.ptr(self._packed), ctypes.c_void_p(stream)),
+                       "nerf_hip_legacy_pack_weights")
         return self._packed
 
     def _table(self, near, far, num_samples, device):

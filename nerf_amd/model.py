@@ -243,40 +243,46 @@ class NeRF(nn.Module):
             order += [heads[slot].weight, heads[slot].bias]
         return order
 
-    def packed_parameters(self):
-        """The parameters re-laid for the kernels (nerf_hip_pack_weights); re-packed whenever a
-        parameter tensor was modified in place or replaced."""
+    def packed_parameters(self, fresh=False):
+        """The parameters re-laid for the kernels (nerf_hip_pack_weights, one 8 us launch).  Re-packed
+        on EVERY call: tensor version counters cannot be trusted to say "unchanged" — fused optimisers
+        (torch.optim.Adam(fused=True)) and ``p.data`` edits update parameters without bumping them,
+        and a stale image is a silently wrong render.  ``fresh``: write into a new buffer (a training
+        forward: its backward reads the image later, after other launches may have re-packed)."""
         self._check_shape()
         params = self._param_list()
         dev = params[0].device
         for p in params:
             _require_device(p, "parameter")
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is None or self._packed_key != key or self._packed.device != dev:
-            lib = _lib.lib()
-            keep = [p.detach().contiguous() for p in params]
-            ptrs = (ctypes.c_void_p * _lib.NUM_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
+        lib = _lib.lib()
+        keep = [p.detach().contiguous() for p in params]
+        ptrs = (ctypes.c_void_p * _lib.NUM_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
+        packed = self._packed
+        if fresh or packed is None or packed.device != dev:
             packed = torch.empty(lib.nerf_hip_packed_bytes() // 4, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(lib.nerf_hip_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
-                           "nerf_hip_pack_weights")
-            self._packed, self._packed_key = packed, key
-        return self._packed
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.nerf_hip_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
+                       "nerf_hip_pack_weights")
+        if not fresh:
+            self._packed = packed
+        self._packed_key = tuple((p.data_ptr(), p._version) for p in params)
+        self._last_packed = packed
+        return packed
 
     def _check_f16x3_range(self, training=False):
         """The split-precision kernel holds 2^8 * w and 2^4 * relu(gamma * x_hat + beta) as f16
         pairs (|x_hat| < 16 for 256 features); refuse parameters that would leave the f16 range
-        instead of saturating silently.  Checked once per parameter version for inference launches;
-        a training forward (new parameter version every optimiser step, and the check is a device ->
-        host copy) re-checks every 64th step: a weight does not grow from O(0.1) to 256 in between."""
+        instead of saturating silently.  The check is a device -> host copy, so it runs when a
+        parameter tensor's version or storage changed and otherwise on every 64th split-precision
+        launch (updates that bypass the version counters — fused optimisers, ``p.data`` — are caught
+        there; a weight does not grow from O(0.1) to 256 within 64 steps).  A training forward, whose
+        versions change with every ordinary optimiser step, only uses the every-64th rule."""
         key = self._packed_key
-        if getattr(self, "_f16x3_checked", None) == key:
+        self._f16x3_calls = getattr(self, "_f16x3_calls", -1) + 1
+        periodic = self._f16x3_calls % 64 == 0
+        if not periodic and (training or getattr(self, "_f16x3_checked", None) == key):
             return
-        if training:
-            self._f16x3_train_calls = getattr(self, "_f16x3_train_calls", -1) + 1
-            if self._f16x3_train_calls % 64 != 0:
-                return
         heads = self.prediction_heads
         with torch.no_grad():                       # one device -> host copy per parameter version
             w_dev = torch.stack([heads[i].weight.abs().max() for i in (0, 3, 6, 9, 12, 15)]).max()
@@ -337,7 +343,7 @@ class NeRF(nn.Module):
                 want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None,
                 train_workspace=None, want_weights=False, cov=None, out_t=None):
         lib = _lib.lib()
-        packed = self.packed_parameters()
+        packed = self.packed_parameters(fresh=train_workspace is not None)
         P = num_samples - 1
         if rgb is None:
             rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)

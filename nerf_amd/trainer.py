@@ -90,7 +90,11 @@ class Trainer:
         self.draws = torch.Generator(device=device).manual_seed(seed + 7919 * (self.rank + 1))
         if self.distributed:
             parallel.broadcast_parameters(self.model)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate)
+        # the reference's optimiser (train_conditional_nerf.py:106); on the GPU in its single-kernel
+        # ("fused") form: the default multi-tensor form is seven launches over the 22 tensors, 0.11 ms of
+        # a 0.8 ms step at 512 rays per GPU
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate,
+                                          fused=next(self.model.parameters()).is_cuda)
         self.reduce = parallel.FlatGradientAllReduce(self.model.parameters())
         self.batch_size = batch_size
         self.num_samples = num_samples_per_ray

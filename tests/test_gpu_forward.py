@@ -337,3 +337,35 @@ def test_f16x3_range_guard_and_training_stays_fp32(dev, precision):
     assert torch.equal(grads["fp32"][0], grads["f16x3"][0])
     for a, b in zip(grads["fp32"][1], grads["f16x3"][1]):
         assert torch.equal(a, b)
+
+
+def test_updates_that_bypass_version_counters_are_rendered(dev):
+    """Fused optimisers and ``p.data`` edits change parameters without bumping ``_version``; the
+    packed image must follow them anyway (it is rebuilt on every launch), in both call styles and
+    through a fused Adam step."""
+    from nerf_amd import NeRF
+    model = make_model(dev, 1.0)
+    g = torch.Generator().manual_seed(5)
+    o = torch.randn(64, 3, generator=g).to(dev)
+    d = torch.randn(64, 3, generator=g).to(dev)
+    with torch.no_grad():
+        before, _ = model.render_rays(o, d, 24)
+        before = before.clone()
+        versions = [p._version for p in model.parameters()]
+        model.prediction_heads[15].weight.data.mul_(1.5)            # .data: no version bump
+        assert [p._version for p in model.parameters()] == versions
+        after, _ = model.render_rays(o, d, 24)
+    assert not torch.equal(before, after)
+    with torch.no_grad():                                            # and it is the CURRENT parameters
+        params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref, _, st = O.render_rays(params, CFG, o.cpu(), d.cpu(), 24, return_stages=True)
+    ok = stable_rays(st["density"][:, -1, 0])
+    assert (after[:, 0].cpu() - ref)[ok].abs().max() <= 1e-5
+
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    pixels, _ = model.render_rays(o, d, 24)
+    (pixels ** 2).mean().backward()
+    opt.step()
+    with torch.no_grad():
+        stepped, _ = model.render_rays(o, d, 24)
+    assert not torch.equal(stepped, after)
