@@ -1109,11 +1109,16 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
     // One k-step: MFMAs on (at[0] of slot 0, bcur) while the VALU builds the next A operands and bnext.
     // at[2]: A operand sets, slot a uses at[a & 1] and converts into at[(a & 1) ^ 1].
     Operand at[2];
-    auto k_step = [&](int64_t t, Operand (&bcur)[Sh::kTi], Operand (&bnext)[Sh::kTi]) {
-        const float* dyt = (const float*)slot_of(t);
-        const float* dyn = (const float*)slot_of(t + 1);
-        const float* xn = (const float*)(slot_of(t + 1) + P::kXOffset);
-        const bool has_next = t + 1 < n_steps;    // else the conversions chew on stale bytes, unused
+    // last_tag: the job's last step converts nothing for a step behind it (its own code instance, so the
+    // steady-state steps carry no selects: a v_cndmask costs 18 cycles here, a plain VALU op 5)
+    auto k_step = [&](auto last_tag, int64_t t, Operand (&bcur)[Sh::kTi], Operand (&bnext)[Sh::kTi]) {
+        constexpr bool kLast = decltype(last_tag)::value;
+        constexpr bool has_next = !kLast;
+        // one lane base per source; everything else in an address is a compile-time constant, so the
+        // reads take immediate offsets (and pair up as ds_read2st64_b32) instead of one v_add each
+        const float* dyt = (const float*)slot_of(t) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
+        const float* dyn = (const float*)slot_of(t + 1) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
+        const float* xn = (const float*)(slot_of(t + 1) + P::kXOffset) + (8 * kk) * Sh::kInW + 32 * in0 + i;
         const bool issue_more = t + 3 < n_steps;
         char* fill = slot_of(t + 3);
 #pragma unroll
@@ -1128,14 +1133,17 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) raw[q][jj] = ga[0] * (float)(jj + q);
 #else
+            const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
+            if (next_a) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc[(8 * kk + jj) * Sh::kOutW + 32 * (out0 + na) + i];
+                for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc[jj * Sh::kOutW + 32 * na];
+            }
 #pragma unroll
             for (int q = 0; q < kBPerSlot; ++q) {
                 const int b = a * kBPerSlot + q;
-                if (b < Sh::kTi) {
+                if (b < Sh::kTi && has_next) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[(8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
+                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[jj * Sh::kInW + 32 * b];
                 }
             }
 #endif
@@ -1145,6 +1153,53 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
             const Operand& ac = at[a & 1];
             Operand& an = at[(a & 1) ^ 1];
             __builtin_amdgcn_sched_barrier(0);
+#ifndef NERF_WGRAD_PINNED
+            if constexpr (kF16) {
+                // f16 form: the slot's 3 kTi MFMAs and its conversions (4 dependent levels per value
+                // pair: scale, pkrtz, residual, pkrtz) handed to the scheduler as ONE region with the
+                // pattern "1 MFMA, then 6 VALU" — pinned value by value (as the bf16 form below does) each
+                // MFMA gap holds one dependent chain, which runs at 1.7x its issue time
+#pragma unroll
+                for (int m = 0; m < kMfmas; ++m) {
+                    const int b = m / kPerProduct, tt = m % kPerProduct;
+                    acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
+                }
+                if (a < 2 && issue_more) {
+                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
+                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
+                }
+#pragma unroll
+                for (int op = 0; op < 1 + kBPerSlot; ++op) {
+                    const int bq = a * kBPerSlot + (op - 1);
+                    if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
+                    if (op == 0 && !next_a) continue;
+                    float v[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        if (op > 0) v[w] = b_value(raw[op][w], bq);
+                        else {
+                            bsum[na] += raw[op][w];       // unscaled: the scaled value then dies in its split
+                            asm("" : "+v"(bsum[na]));     // (keeps SLP from pairing the adds into v_pk_add_f32
+                                                          //  with an op_sel swap: isa_hazards.py rule R5)
+                            v[w] = raw[op][w] * a_scale;
+                        }
+                    }
+                    Operand r;
+                    split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, r.h, r.l);
+                    if (op == 0) an = r;
+                    else bnext[bq] = r;
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8 * (1 + kBPerSlot), 0);     // the raw LDS reads (at most)
+#pragma unroll
+                for (int m = 1; m < kMfmas; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int m = 0; m < kMfmas; ++m) {
                 const int b = m / kPerProduct, tt = m % kPerProduct;
@@ -1165,7 +1220,8 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                     if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
                     const int op = it / kItemsPerOp, w = it % kItemsPerOp;   // op 0: next A operand, 1..: B operands of step t + 1
                     const int bq = a * kBPerSlot + (op - 1);
-                    if (op > 0 && bq >= Sh::kTi) continue;
+                    if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
+                    if (op == 0 && !next_a) continue;
                     if constexpr (kF16) {
                         if (w < 4) {                  // values 2w, 2w + 1: scale (dY) or affine + ReLU (X)
 #pragma unroll
@@ -1174,8 +1230,8 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                                 asm volatile("" : "+v"(val));
                                 if (op > 0) val = b_value(val, bq);
                                 else {
+                                    bsum[na] += val;
                                     val *= a_scale;
-                                    bsum[na] += (a + 1 < Sh::kTo || has_next) ? val : 0.f;
                                 }
                                 asm volatile("" : "+v"(val));
                                 raw[op][2 * w + e2] = val;
@@ -1206,7 +1262,7 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                         asm volatile("" : "+v"(val));
                         if (op > 0) val = b_value(val, bq);
                         // bias gradient: every dY value of the wave's out tiles is converted exactly once
-                        if (op == 0) bsum[na] += (a + 1 < Sh::kTo || has_next) ? val : 0.f;
+                        if (op == 0) bsum[na] += val;
                         th[op][w] = __builtin_bit_cast(unsigned, val) & 0xffff0000u;
                         const float r1 = val - __builtin_bit_cast(float, th[op][w]);
                         tm[op][w] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
@@ -1279,15 +1335,20 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
             float v[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                v[jj] = dyt[(8 * kk + jj) * Sh::kOutW + 32 * out0 + i] * a_scale;
+                v[jj] = dyt[(8 * kk + jj) * Sh::kOutW + 32 * out0 + i];
                 bsum[0] += v[jj];
+                v[jj] *= a_scale;
             }
             at[0] = convert(v);
         }
-        for (int64_t t = 0; t < n_steps; t += 2) {    // two steps per trip: the B sets swap roles
-            k_step(t, b0, b1);
-            k_step(t + 1, b1, b0);
+        const std::false_type more_steps;
+        const std::true_type last_step;
+        for (int64_t t = 0; t + 2 < n_steps; t += 2) {    // two steps per trip: the B sets swap roles
+            k_step(more_steps, t, b0, b1);
+            k_step(more_steps, t + 1, b1, b0);
         }
+        k_step(more_steps, n_steps - 2, b0, b1);
+        k_step(last_step, n_steps - 1, b1, b0);
     }
 
     float* slab = ba.slabs + (int64_t)split * kSlabFloats;
@@ -1301,11 +1362,10 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r] * un_scale;
             }
-    const float un_bias = kF16 ? un_scale * (float)(1 << kXScaleLog2) : 1.0f;      // the bias sums carry dY's scale only
 #pragma unroll
     for (int a = 0; a < Sh::kTo; ++a) {
         const float both = bsum[a] + __shfl_xor(bsum[a], 32);       // the two 8-sample halves of a k-step
-        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both * un_bias;
+        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both;
     }
 }
 

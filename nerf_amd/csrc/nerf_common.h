@@ -156,6 +156,9 @@ inline const char* build_flags() {
 #ifdef NERF_WGRAD_TILE32
            "NERF_WGRAD_TILE32 "
 #endif
+#ifdef NERF_WGRAD_PINNED
+           "NERF_WGRAD_PINNED "
+#endif
 #ifdef NERF_WGRAD_BF16_ONLY
            "NERF_WGRAD_BF16_ONLY "
 #endif

@@ -18,5 +18,5 @@ pass write WRITE_SIZE
 summ() { python3 scripts/pmc_summary.py $OUT/${TAG}_a $OUT/${TAG}_d $OUT/${TAG}_b $OUT/${TAG}_fetch $OUT/${TAG}_write --kernel "$2" > $OUT/${TAG}_$1_pmc.json; }
 summ fwd "nerf_render_fwd_kernel<true"
 summ dgrad nerf_bwd_data_
-summ wgrad nerf_wgrad_kernel
+summ wgrad nerf_wgrad_
 grep -h "nerf_\|Name" $OUT/${TAG}_trace/*kernel_stats.csv | head -12
