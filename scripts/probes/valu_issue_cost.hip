@@ -30,12 +30,18 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define I_CNDMASK(c) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(q[c]) : "v"(r[c]), "v"(k0) : "vcc");
 #define I_PKFMA(c) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[c]) : "v"(kk));
 #define I_EXP(c) asm volatile("v_exp_f32 %0, %1" : "=v"(q[c]) : "v"(r[c]));
+#define I_CND3(c) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(q[c]) : "v"(r[c]), "v"(k0), "s"(mask64));
+#define I_CMPCND(c) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %1, vcc" : "=v"(q[c]) : "v"(r[c]), "v"(k1) : "vcc");
+#define I_CMPCND3(c) asm volatile("v_cmp_gt_f32_e64 %3, %1, %2\n\tv_cndmask_b32_e64 %0, 0, %1, %3" : "=v"(q[c]), "+s"(mask64) : "v"(r[c]), "v"(k1));
+#define I_MASKAND(c) asm volatile("v_sub_u32 %0, 0, %1\n\tv_ashrrev_i32 %0, 31, %0\n\tv_and_b32 %0, %0, %2" : "=&v"(q[c]) : "v"(r[c]), "v"(k0));
+#define I_MULCLAMP(c) asm volatile("v_mul_f32_e64 %0, %1, %2 clamp\n\tv_mul_f32 %0, %0, %3" : "=&v"(q[c]) : "v"(r[c]), "v"(k0), "v"(k1));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int kForm>
 __device__ __forceinline__ void sixteen(float (&r)[16], float (&q)[16], f32x2 (&p2)[16], float k0, float k1, f32x2 kk,
                                         uint32_t sel) {
+    uint64_t mask64 = 0x5555555555555555ull;
     if (kForm == 0) { REP16(I_ADD) }
     if (kForm == 1) { REP16(I_FMA) }
     if (kForm == 2) { REP16(I_MUL) }
@@ -52,14 +58,20 @@ __device__ __forceinline__ void sixteen(float (&r)[16], float (&q)[16], f32x2 (&
     if (kForm == 13) { REP16(I_CNDMASK) }
     if (kForm == 14) { REP16(I_PKFMA) }
     if (kForm == 15) { REP16(I_EXP) }
+    if (kForm == 16) { REP16(I_CND3) }
+    if (kForm == 17) { REP16(I_CMPCND) }
+    if (kForm == 18) { REP16(I_MASKAND) }
+    if (kForm == 19) { REP16(I_MULCLAMP) }
     // all sixteen results stay live to here: distinct destination registers, no WAW chain on one
 #define KEEP(c) asm volatile("" ::"v"(q[c]));
     REP16(KEEP)
 }
 
-static const char* kNames[16] = {"v_add_f32", "v_fma_f32", "v_mul_f32", "v_max_f32", "v_mov_b32", "v_and_b32 literal",
+static const char* kNames[20] = {"v_add_f32", "v_fma_f32", "v_mul_f32", "v_max_f32", "v_mov_b32", "v_and_b32 literal",
                                  "v_sub_f32", "v_perm_b32", "v_cvt_pkrtz_f16_f32", "v_fma_mix_f32 lo", "v_fma_mix_f32 hi",
-                                 "v_cvt_pk_bf16_f32", "v_add_f32_dpp", "v_cndmask_b32", "v_pk_fma_f32", "v_exp_f32"};
+                                 "v_cvt_pk_bf16_f32", "v_add_f32_dpp", "v_cndmask_b32 (vcc)", "v_pk_fma_f32", "v_exp_f32",
+                                 "v_cndmask_b32_e64 (sgpr pair)", "v_cmp + v_cndmask (2 instr)", "sub+ashr+and (3 instr)",
+                                 "mul clamp + mul (2 instr)"};
 
 template <int kForm>
 __global__ __launch_bounds__(256, 1) void alone(float* out, unsigned long long* cycles, int iters) {
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void alone(float* out, unsigned long long* 
     float s = 0.f;
     for (int c = 0; c < 16; ++c) s += r[c] + q[c] + p2[c].x;
     out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cycles[kForm] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cycles[kForm] = t1 - t0;   // (two-instruction forms: per PAIR/TRIPLE)
 }
 
 // 1 MFMA + kFill fillers of form kForm per gap
@@ -159,12 +171,13 @@ int main() {
     float* out;
     unsigned long long* cyc;
     hipMalloc(&out, 256 * 256 * 4);
-    hipMalloc(&cyc, 16 * 8);
+    hipMalloc(&cyc, 32 * 8);
     printf("(ticks of __builtin_readcyclecounter = s_memtime; compare forms with each other)\n");
     run_alone<0>(out, cyc); run_alone<1>(out, cyc); run_alone<2>(out, cyc); run_alone<3>(out, cyc);
     run_alone<4>(out, cyc); run_alone<5>(out, cyc); run_alone<6>(out, cyc); run_alone<7>(out, cyc);
     run_alone<8>(out, cyc); run_alone<9>(out, cyc); run_alone<10>(out, cyc); run_alone<11>(out, cyc);
     run_alone<12>(out, cyc); run_alone<13>(out, cyc); run_alone<14>(out, cyc); run_alone<15>(out, cyc);
+    run_alone<16>(out, cyc); run_alone<17>(out, cyc); run_alone<18>(out, cyc); run_alone<19>(out, cyc);
     run_gap<0, 0>(out, cyc, "-");
     run_gap<0, 2>(out, cyc, "v_add_f32"); run_gap<0, 4>(out, cyc, "v_add_f32"); run_gap<0, 6>(out, cyc, "v_add_f32");
     run_gap<0, 8>(out, cyc, "v_add_f32");

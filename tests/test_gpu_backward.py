@@ -157,3 +157,59 @@ def test_no_grad_path_skips_the_workspace(dev):
     assert not rgb.requires_grad
     rgb2, _ = model.render_rays(o, d, 16)
     assert rgb2.requires_grad and torch.equal(rgb, rgb2.detach())
+
+
+@pytest.mark.parametrize("loss_scale", [2.0 ** -60, 2.0 ** 60, 1e-18, 1e18])
+def test_gradients_are_linear_in_the_loss_scale(dev, loss_scale):
+    """The split-precision backward multiplies dY by powers of two (per sample in the data gradient,
+    per layer and batch in the weight gradient) and divides them out again: over 36 orders of magnitude
+    of the loss the gradients must only scale."""
+    torch.manual_seed(11)
+    model = make_model(dev, golden_params(2.0))
+    n, S = 96, 48
+    o, d = torch.randn(n, 3).to(dev), torch.randn(n, 3).to(dev)
+    u = torch.rand(n, S).to(dev)
+    target = torch.rand(n, 3, device=dev)
+
+    def grads(scale):
+        model.zero_grad(set_to_none=True)
+        rgb, seg = model.render_rays(o, d, S, randomly_sample=True, u=u)
+        loss = ((rgb[:, 0] - target) ** 2).sum() + 1e-3 * (seg[:, 0] ** 2).sum()
+        (loss * scale).backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    base, mine = grads(1.0), grads(loss_scale)
+    for g, b in zip(mine, base):
+        assert torch.isfinite(g).all()
+        assert rel_err(g / loss_scale, b) <= 1e-6         # (not bitwise: the compositing backward's 1e-10
+                                                          #  guards and underflow at 2^-60 are not scale-free)
+
+
+def test_gradients_of_a_batch_with_twelve_orders_of_dynamic_range(dev):
+    """Rays weighted 1e-6 ... 1e6 in one batch: the weight gradient's ONE scale per layer serves them
+    all; held to the oracle like every other gradient test (8 x the input's fp32 noise floor)."""
+    torch.manual_seed(12)
+    params = golden_params(2.0)
+    n, S = 96, 40
+    o, d = torch.randn(n, 3), torch.randn(n, 3)
+    u = torch.rand(n, S)
+    w = torch.ones(n, 1)
+    w[: n // 3] = 1e-6
+    w[n // 3: 2 * n // 3] = 1e6
+    target = torch.rand(n, 3)
+
+    def loss_of(rgb, seg, cast):
+        return (cast(w) * (rgb - cast(target)) ** 2).sum() + 1e-3 * (cast(w) * seg ** 2).sum()
+
+    ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    rgb_r, seg_r = O.render_rays(ref, CFG, o, d, S, u=u)
+    loss_of(rgb_r, seg_r, lambda t: t).backward()
+    exact = fp64_gradients(params, lambda p: loss_of(*O.render_rays(p, CFG, o.double(), d.double(), S, u=u.double()),
+                                                     lambda t: t.double()))
+    model = make_model(dev, params)
+    rgb, seg = model.render_rays(o.to(dev), d.to(dev), S, randomly_sample=True, u=u.to(dev))
+    loss_of(rgb[:, 0], seg[:, 0], lambda t: t.to(dev)).backward()
+    noise_floor = max(rel_err(ref[k].grad, exact[k]) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad.cpu(), ref[k].grad)
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
