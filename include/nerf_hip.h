@@ -112,7 +112,9 @@ typedef struct NerfHipRenderArgs {
      * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats      */
     float* train_workspace;
     /* arithmetic of the MLP.  On a training forward it also selects the arithmetic of the data
-     * gradient (dX = W^T dY) in nerf_hip_render_backward, which reads this struct back:
+     * gradient (dX = W^T dY) and of the weight gradient (dW = dY^T X; f16 pairs with one power-of-two
+     * scale per layer and batch, else bf16 triples) in nerf_hip_render_backward, which reads this
+     * struct back:
      * FP32  = exact-fp32 MFMA, the reference's arithmetic (torch fp32, nerf/model.py:525-542);
      * F16X3 = every fp32 operand split into an f16 pair, three f16 MFMAs per product with fp32
      *         accumulation (~2^-22 relative per product; same 1e-4 RGB parity bar)            */
