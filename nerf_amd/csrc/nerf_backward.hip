@@ -727,217 +727,9 @@ __device__ __forceinline__ f32x16 mfma_bf(const bf8& a, const bf8& b, const f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <class Sh, bool kAffine>
-__device__ __forceinline__ void wgrad_body_bf16(const BwdArgs& ba, char* smem, const float* dy, const float* x,
-                                                const float* small_prev, int w_off, int b_off, int split) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    int out0, in0;                                // first 32-wide tile of this wave
-    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
-    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
-    else { out0 = 0; in0 = 2 * wave; }
-
-    float ga[Sh::kTi], be[Sh::kTi];
-#pragma unroll
-    for (int b = 0; b < Sh::kTi; ++b) {
-        const int f = 32 * (in0 + b) + (lane & 31);
-        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
-        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
-        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
-    }
-
-    f32x16 acc[Sh::kTo][Sh::kTi];
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // bias gradient = column sums of dY: summed from the A-operand values as they are converted
-    // (every dY element of the wave's out tiles passes through exactly once per tile); waves that
-    // share their out tiles with another wave leave it to the one with in0 == 0
-    float bsum[Sh::kTo];
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a) bsum[a] = 0.f;
-
-    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
-    int64_t tile_end = tile_begin + ba.tiles_per_split;
-    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
-    const int64_t nt = tile_end > tile_begin ? tile_end - tile_begin : 0;
-    const int i = lane & 31, kk = lane >> 5;
-    constexpr int kSteps = kKs / 16;              // MFMA k-steps per LDS tile
-    // the next tile's DMA pieces go out in the FIRST HALF of this tile's slots, so that the last of
-    // them has half a tile of MFMAs to land before the tile hand-over waits for it
-    constexpr int kIssueSlots = kSteps * Sh::kTo / 2;
-    constexpr int kPerSlot = (Sh::kPiecesPerWave + kIssueSlots - 1) / kIssueSlots;
-
-    if (nt > 0) wgrad_issue<Sh>(dy, x, tile_begin * kKs, smem, wave, lane);
-    for (int64_t k = 0; k < nt; ++k) {
-        char* cur = smem + (k & 1) * Sh::kTileBytes;
-        char* nxt_buf = smem + ((k + 1) & 1) * Sh::kTileBytes;
-        const bool more = k + 1 < nt;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const float* dyt = (const float*)cur;
-        const float* xt = (const float*)(cur + Sh::kDyBytes);
-        auto b_terms = [&](int step, int b) {     // relu(gamma x_hat + beta) (or the encoded inputs), split
-            float v[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float raw = xt[(16 * step + 8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
-                v[jj] = kAffine ? __builtin_fmaxf(__builtin_fmaf(raw, ga[b], be[b]), 0.f) : raw;
-            }
-            return split_bf3(v);
-        };
-        auto a_terms = [&](int step, int a) {
-            float v[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                v[jj] = dyt[(16 * step + 8 * kk + jj) * Sh::kOutW + 32 * (out0 + a) + i];
-                bsum[a] += v[jj];
-            }
-            return split_bf3(v);
-        };
-        // Software pipeline over the tile's kSteps x kTo slots: while the 6 kTi MFMAs of slot
-        // (step, a) issue, the VALU converts the A operand of the next slot and this slot's share of
-        // the next k-step's B operands, one value (or two) behind each MFMA — spelled out MFMA by
-        // MFMA with scheduling fences, because the scheduler otherwise clumps every conversion in
-        // front of the MFMA batch (one wave per SIMD here: nothing else would fill the matrix pipe
-        // meanwhile).  Exposed per tile: the first k-step's B operands and the first A operand.
-        Bf3 bt[Sh::kTi], bn[Sh::kTi];
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b) bt[b] = b_terms(0, b);
-        Bf3 at = a_terms(0, 0), an;
-        constexpr int kBPerSlot = (Sh::kTi + Sh::kTo - 1) / Sh::kTo;
-        constexpr int kMfmas = 6 * Sh::kTi;                       // per slot
-        constexpr int kLead = kMfmas / 6;       // MFMAs issued before the first conversion (the slot's
-                                                // LDS reads land under them)
-        constexpr int kItems = 10 * (1 + kBPerSlot);              // 8 values + 2 packing items per operand
-#pragma unroll
-        for (int step = 0; step < kSteps; ++step) {
-#pragma unroll
-            for (int a = 0; a < Sh::kTo; ++a) {
-                const bool last_slot = step == kSteps - 1 && a == Sh::kTo - 1;
-                const bool next_b = step + 1 < kSteps;
-                // the next tile's LDS-DMA pieces, a few per slot
-                if (more) {
-#pragma unroll
-                    for (int q = 0; q < kPerSlot; ++q) {
-                        const int piece = (step * Sh::kTo + a) * kPerSlot + q;
-                        if (piece < Sh::kPiecesPerWave)
-                            wgrad_issue_piece<Sh>(dy, x, (tile_begin + k + 1) * kKs, nxt_buf, wave, lane, piece);
-                    }
-                }
-                // raw operands of what this slot converts (LDS reads issued up front)
-                float raw[1 + kBPerSlot][8];
-                const int na = a + 1 < Sh::kTo ? a + 1 : 0, ns = a + 1 < Sh::kTo ? step : step + 1;
-                if (!last_slot) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj)
-                        raw[0][jj] = dyt[(16 * ns + 8 * kk + jj) * Sh::kOutW + 32 * (out0 + na) + i];
-                }
-                if (next_b) {
-#pragma unroll
-                    for (int q = 0; q < kBPerSlot; ++q) {
-                        const int b = a * kBPerSlot + q;
-                        if (b < Sh::kTi) {
-#pragma unroll
-                            for (int jj = 0; jj < 8; ++jj)
-                                raw[1 + q][jj] = xt[(16 * (step + 1) + 8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i];
-                        }
-                    }
-                }
-                unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
-                u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < kMfmas; ++m) {
-                    const int b = m / 6, t = m % 6;
-                    const bf8& ta = t == 5 ? at.l : (t == 2 || t == 3 ? at.m : at.h);
-                    const bf8& tb = t == 4 ? bt[b].l : (t == 1 || t == 3 ? bt[b].m : bt[b].h);
-                    acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // This MFMA's share of the slot's conversions.  Work items, per operand: its 8
-                    // values (one dependent chain of ~5-7 VALU each), then two items of 6 byte-permutes
-                    // that pack the halves; spread evenly over the MFMAs behind the first kLead (whose
-                    // shadow covers the latency of the slot's LDS reads).  One wave per SIMD: an MFMA
-                    // can only start when the VALU work in front of it is done, so every gap must
-                    // stay under one MFMA (32 cycles ~ 6-7 VALU), not just the average.
-#pragma unroll
-                    for (int it = 0; it < kItems; ++it) {
-                        if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
-                        const int op = it / 10, w = it % 10;       // op 0: next A tile, 1..: B tiles
-                        const int bq = a * kBPerSlot + (op - 1);
-                        const bool live = op == 0 ? !last_slot : (next_b && bq < Sh::kTi);
-                        if (!live) continue;
-                        if (w < 8) {
-                            float val = raw[op][w];
-                            // (volatile asm in and out: plain arithmetic floats across the
-                            // scheduling fences, these two pin the value's conversion to this gap)
-                            asm volatile("" : "+v"(val));
-                            if (op > 0 && kAffine) val = __builtin_fmaxf(__builtin_fmaf(val, ga[bq], be[bq]), 0.f);
-                            if (op == 0) bsum[na] += val;
-                            th[op][w] = __builtin_bit_cast(unsigned, val) & 0xffff0000u;
-                            const float r1 = val - __builtin_bit_cast(float, th[op][w]);
-                            tm[op][w] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-                            tl[op][w] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, tm[op][w]));
-                            asm volatile("" : "+v"(tl[op][w]));
-                        } else {
-#pragma unroll
-                            for (int p = 2 * (w - 8); p < 2 * (w - 8) + 2; ++p) {
-                                unsigned lo_h = th[op][2 * p], lo_m = tm[op][2 * p], lo_l = tl[op][2 * p];
-                                asm volatile("" : "+v"(lo_h), "+v"(lo_m), "+v"(lo_l));
-                                ph[op][p] = __builtin_amdgcn_perm(th[op][2 * p + 1], lo_h, 0x07060302u);
-                                pm[op][p] = __builtin_amdgcn_perm(tm[op][2 * p + 1], lo_m, 0x07060302u);
-                                pl[op][p] = __builtin_amdgcn_perm(tl[op][2 * p + 1], lo_l, 0x07060302u);
-                                asm volatile("" : "+v"(ph[op][p]), "+v"(pm[op][p]), "+v"(pl[op][p]));
-                            }
-                            if (w == 9) {
-                                Bf3 r;
-                                r.h = __builtin_bit_cast(bf8, ph[op]);
-                                r.m = __builtin_bit_cast(bf8, pm[op]);
-                                r.l = __builtin_bit_cast(bf8, pl[op]);
-                                if (op == 0) an = r;
-                                else bn[bq] = r;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (!last_slot) at = an;
-            }
-            if (step + 1 < kSteps) {
-#pragma unroll
-                for (int b = 0; b < Sh::kTi; ++b) bt[b] = bn[b];
-            }
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
-    const int col = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r];
-            }
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a) {
-        const float both = bsum[a] + __shfl_xor(bsum[a], 32);       // the two 8-sample halves of a k-step
-        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // The bf16-triple GEMM as ONE continuous stream of 16-sample k-steps over a 4-slot LDS ring
-// (round 2; the 32-sample double-buffered form above is kept behind -DNERF_WGRAD_TILE32).
+// (round 2; round 1's form — 32-sample tiles in two buffers — is in the history: commit 39d705c).
 // Why: with one wave per SIMD nothing hides a tile hand-over.  The two-buffer form exposed, per
 // 32-sample tile, the conversion of the tile's first operands (5 operands x 8 values x ~7 VALU)
 // and a vmcnt(0) that waited for a tile whose DMA had been issued only half a tile earlier; the
@@ -1371,8 +1163,6 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
 
 #if defined(NERF_WGRAD_FP32)    /* the exact-fp32 32x32x2 GEMM (kept as the comparison build) */
 #define WGRAD_BODY wgrad_body
-#elif defined(NERF_WGRAD_TILE32) /* bf16 triples, 32-sample tiles in two buffers (round-1 form) */
-#define WGRAD_BODY wgrad_body_bf16
 #else
 #define WGRAD_BODY wgrad_body_ring
 #endif
@@ -1592,7 +1382,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
 #else
     const int wgrad_jobs = 6;
 #endif
-#if defined(NERF_WGRAD_FP32) || defined(NERF_WGRAD_TILE32) || defined(NERF_WGRAD_BF16_ONLY)
+#if defined(NERF_WGRAD_FP32) || defined(NERF_WGRAD_BF16_ONLY)
     const bool wgrad_half = false;
 #else
     const bool wgrad_half = half;

@@ -153,9 +153,6 @@ inline const char* build_flags() {
 #ifdef NERF_WGRAD_FP32
            "NERF_WGRAD_FP32 "
 #endif
-#ifdef NERF_WGRAD_TILE32
-           "NERF_WGRAD_TILE32 "
-#endif
 #ifdef NERF_WGRAD_PINNED
            "NERF_WGRAD_PINNED "
 #endif
