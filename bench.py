@@ -133,10 +133,63 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
-            "arithmetic": ("training forward and data gradient on f16 pairs (three f16 MFMAs per product), "
-                           if train_precision == "f16x3" else "training forward and data gradient on fp32 MFMA, ")
-                          + "weight gradient on bf16 triples (six bf16 MFMAs per product); fp32 accumulate "
-                            "everywhere"}
+            "arithmetic": ("training forward, data gradient and weight gradient on f16 pairs (three f16 MFMAs per "
+                           "product; layer 0's weight gradient on bf16 triples); fp32 accumulate everywhere"
+                           if train_precision == "f16x3" else
+                           "training forward and data gradient on fp32 MFMA, weight gradient on bf16 triples (six "
+                           "bf16 MFMAs per product); fp32 accumulate everywhere")}
+
+
+def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision="f16x3"):
+    """BASELINE config 5's share per GPU on 8 GPUs (512 rays x 64): one optimiser step eagerly and as ONE
+    HIP-graph replay (forward + loss + backward + fused Adam, draws from torch's graph-safe generator) —
+    the path nerf_amd.trainer.Trainer(graph=True) takes; at this size launches, not kernels, set the pace."""
+    from nerf_amd import NeRF
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    model.train_precision = train_precision
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+    o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
+    target = torch.rand(rays, 3, device=dev)
+
+    def step():
+        u = torch.rand(rays, samples, device=dev)
+        noise = torch.randn(rays, samples - 1, 1, device=dev)
+        pixels, _ = model.render_rays(o, d, samples, randomly_sample=True, density_noise_std=1.0, u=u, noise=noise)
+        loss = ((pixels - target.unsqueeze(1)) ** 2).mean()
+        loss.backward()
+        opt.step()
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        step()
+
+    for _ in range(3):
+        eager()
+    t_eager = timed(eager)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    graph.replay()
+    t_graph = timed(graph.replay)
+    return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam, {train_precision}",
+            "ms_per_step_eager": t_eager * 1e3, "ms_per_step_graph": t_graph * 1e3,
+            "ray_samples_per_s_graph": rays * samples / t_graph}
 
 
 def legacy_workload_timing(dev, steps=3, warmup=1):
@@ -370,6 +423,7 @@ def main():
             }
             line["train_step"] = train_step_timing(dev)
             line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
+            line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -278,6 +278,9 @@ class NeRF(nn.Module):
         launch (updates that bypass the version counters — fused optimisers, ``p.data`` — are caught
         there; a weight does not grow from O(0.1) to 256 within 64 steps).  A training forward, whose
         versions change with every ordinary optimiser step, only uses the every-64th rule."""
+        if torch.cuda.is_current_stream_capturing():
+            return                                   # no host sync inside a HIP-graph capture (the trainer
+                                                     # re-checks between replays, Trainer.train_step)
         key = self._packed_key
         self._f16x3_calls = getattr(self, "_f16x3_calls", -1) + 1
         periodic = self._f16x3_calls % 64 == 0
@@ -293,6 +296,12 @@ class NeRF(nn.Module):
             raise ValueError(f"nerf_amd: parameters out of range for precision='f16x3' (max |w| {w_max:.3g}, "
                              f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
         self._f16x3_checked = key
+
+    def check_split_precision_range(self):
+        """Force the f16 range check of the parameters now (raises ValueError when they left it)."""
+        self._f16x3_checked = None
+        self._f16x3_calls = -1
+        self._check_f16x3_range(training=False)
 
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
                    cameras=None, ray_begin=0, t_values=None, u=None, noise=None,

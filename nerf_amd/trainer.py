@@ -67,7 +67,7 @@ def load_scene(path, device):
 class Trainer:
     def __init__(self, images, poses, focal_length, logging_dir=None, batch_size=1024,
                  learning_rate=1e-4, num_samples_per_ray=64, density_noise_std=1.0, log_interval=1000,
-                 segmentation=None, model=None, seed=0, rng="torch"):
+                 segmentation=None, model=None, seed=0, rng="torch", graph=False):
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if self.distributed else 0
         self.world = dist.get_world_size() if self.distributed else 1
@@ -93,8 +93,22 @@ class Trainer:
         # the reference's optimiser (train_conditional_nerf.py:106); on the GPU in its single-kernel
         # ("fused") form: the default multi-tensor form is seven launches over the 22 tensors, 0.11 ms of
         # a 0.8 ms step at 512 rays per GPU
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate,
-                                          fused=next(self.model.parameters()).is_cuda)
+        # graph: replay forward + loss + backward (+ the optimiser step when single-process) as ONE HIP
+        # graph per iteration.  At 512 rays per GPU (BASELINE config 5 on 8 GPUs) a step is launch-bound:
+        # ~27 kernel launches and the autograd hop cost more than the 0.33 ms the kernels run
+        # (0.64 -> 0.46 ms per step, scripts/graph_step.py).
+        on_gpu = next(self.model.parameters()).is_cuda
+        self.use_graph = bool(graph) and on_gpu
+        self._graph = None
+        self._graph_rays = -1
+        self._eager_steps = 0
+        if self.use_graph:
+            if rng != "torch":
+                raise ValueError("graph=True needs rng='torch': the in-kernel Philox offset is a launch "
+                                 "argument, a replayed launch would repeat its draws")
+            torch.cuda.manual_seed(seed + 7919 * (self.rank + 1))      # draws come from the default generator
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate, fused=on_gpu,
+                                          capturable=self.use_graph and not self.distributed)
         self.reduce = parallel.FlatGradientAllReduce(self.model.parameters())
         self.batch_size = batch_size
         self.num_samples = num_samples_per_ray
@@ -104,6 +118,7 @@ class Trainer:
         self.sampler = torch.Generator(device=device).manual_seed(seed)     # same order on all ranks
         self.psnrs, self.iternums, self.rendered, self.truth = [], [], [], []
         self.iteration = -1
+        self._side = None
         if logging_dir is not None and self.rank == 0:
             os.makedirs(logging_dir, exist_ok=True)
 
@@ -112,7 +127,69 @@ class Trainer:
             with open(os.path.join(self.logging_dir, "params.json"), "w") as f:
                 json.dump(params, f, indent=4)
 
+    # ---- HIP-graph path ---------------------------------------------------------------------------
+    def _graph_body(self, o, d, pix):
+        n, dev = o.shape[0], o.device
+        u = torch.rand(n, self.num_samples, dtype=torch.float32, device=dev)           # graph-safe default
+        noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32, device=dev)   # generator
+        pixels, _ = self.model.render_rays(o, d, self.num_samples, randomly_sample=True,
+                                           density_noise_std=self.density_noise_std, u=u,
+                                           noise=noise if self.density_noise_std != 0.0 else None)
+        loss = ((pixels - pix.unsqueeze(1)) ** 2).sum() / max(3 * n, 1)
+        loss.backward()
+        if not self.distributed:
+            self.optimizer.step()
+        return loss.detach()
+
+    def _graph_step(self, batch):
+        """Steps 0-2 run eagerly (lazy initialisation, optimiser state), steps 3-4 eagerly on the side
+        stream the capture will use (autograd's accumulation nodes must live there), step 5 is captured
+        and from then on every full-size batch is a copy into the static inputs + one replay."""
+        n = batch["rays_o"].shape[0]
+        if self._graph is not None and n != self._graph_rays:
+            return None                                   # tail batch of an epoch: eager
+        if self._graph is None and self._eager_steps < 5:
+            self._eager_steps += 1
+            if self._eager_steps <= 3:
+                return None
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=batch["rays_o"].device)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self._graph_body(batch["rays_o"], batch["rays_d"], batch["pixels"])
+                if self.distributed:
+                    self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
+                    self.optimizer.step()
+            torch.cuda.current_stream().wait_stream(self._side)
+            return loss
+        if self._graph is None:
+            self._static = {k: batch[k].clone() for k in ("rays_o", "rays_d", "pixels")}
+            self.optimizer.zero_grad(set_to_none=True)    # the gradients are created inside the graph's pool
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=self._side):
+                self._static_loss = self._graph_body(self._static["rays_o"], self._static["rays_d"],
+                                                     self._static["pixels"])
+            self._graph_rays = n
+            self._static_grads = [p.grad for p in self.model.parameters()]
+            self._static_flat = self.model.last_flat_grad
+        for k, t in self._static.items():
+            t.copy_(batch[k])
+        self._graph.replay()
+        if self.distributed:
+            for p, g in zip(self.model.parameters(), self._static_grads):
+                p.grad = g                                # an eager tail step may have replaced them
+            self.reduce(self._static_flat, n / max(int(batch.get("global_n", n * self.world)), 1))
+            self.optimizer.step()
+        if self.model.train_precision == "f16x3" and self.iteration % 64 == 0:
+            self.model.check_split_precision_range()      # the replay runs no host code
+        return self._static_loss
+
     def train_step(self, batch):
+        if self.use_graph:
+            loss = self._graph_step(batch)
+            if loss is not None:
+                return loss
         n = batch["rays_o"].shape[0]
         u = noise = None
         if self.model.rng == "torch" and self.distributed:

@@ -85,6 +85,40 @@ def test_training_improves_held_out_psnr_and_writes_reference_files(tmp_path):
     assert list(state.keys())[:3] == ["rays_min", "rays_max", "prediction_heads.0.weight"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+def test_graph_replayed_training_fits_like_the_eager_loop(train_precision):
+    """Trainer(graph=True): after five eager steps every full batch is one HIP-graph replay (forward,
+    loss, backward, fused Adam).  It must train — same fit as the eager loop within noise — draw new
+    stratified samples on every replay, and fall back to eager for the epoch's short tail batch."""
+    from nerf_amd import trainer as T
+    dev = torch.device("cuda:0")
+    images, poses, focal = T.synthetic_scene(num_views=9, size=24, num_samples=32, device=dev)
+    losses = {}
+    for graph in (False, True):
+        run = T.Trainer(images, poses, focal, batch_size=512, learning_rate=5e-4, num_samples_per_ray=32,
+                        density_noise_std=0.0, log_interval=10 ** 9, seed=1, graph=graph)
+        run.model.train_precision = train_precision
+        first = float(run.fit(epochs=1, max_iterations=1))
+        last = float(run.fit(epochs=1000, max_iterations=601))     # 4,608 rays per epoch: 9 x 512, no tail
+        losses[graph] = (first, last)
+        if graph:
+            assert run._graph is not None and run._graph_rays == 512
+            before = run._static_loss.clone()
+            run._graph.replay()                                    # same batch again: new draws, new step
+            torch.cuda.synchronize()
+            assert not torch.equal(before, run._static_loss)
+    assert losses[True][1] < 0.1 * losses[True][0]
+    assert abs(losses[True][1] - losses[False][1]) < 0.5 * losses[False][1] + 1e-4
+
+    # an epoch with a short tail (batch 500 of 4,608 rays -> tail of 108): the tail runs eagerly
+    run = T.Trainer(images, poses, focal, batch_size=500, learning_rate=5e-4, num_samples_per_ray=32,
+                    density_noise_std=0.0, log_interval=10 ** 9, seed=1, graph=True)
+    run.model.train_precision = train_precision
+    last = float(run.fit(epochs=3))
+    assert run._graph_rays == 500 and last == last and last < 1.0
+
+
 def test_load_scene_reads_the_tiny_nerf_layout(tmp_path):
     """tiny_nerf_data.npz (examples/, not shipped: .MISSING_LARGE_BLOBS) holds images [V,H,W,3],
     poses [V,4,4] and a scalar focal; the loader must take a file of that layout (any float dtype)."""

@@ -29,9 +29,15 @@ if __name__ == "__main__":
     ap.add_argument("--log-interval", type=int, default=1000)
     ap.add_argument("--max-iterations", type=int, default=None)
     ap.add_argument("--rng", choices=("torch", "philox"), default="philox")
-    # arithmetic of the MLP in the held-out renders; training steps run fp32 / bf16x6
+    # arithmetic of the MLP in the held-out renders ...
     ap.add_argument("--precision", choices=("fp32", "f16x3"), default="fp32")
+    # ... and of the training steps: forward, data and weight gradient
+    ap.add_argument("--train-precision", choices=("fp32", "f16x3"), default="fp32")
+    # replay each training step as one HIP graph (launch-bound small batches; implies --rng torch)
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
+    if args.graph:
+        args.rng = "torch"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -47,8 +53,9 @@ if __name__ == "__main__":
     run = T.Trainer(images, poses, focal, logging_dir=args.logging_dir, batch_size=args.batch_size,
                     learning_rate=args.learning_rate, num_samples_per_ray=args.num_samples_per_ray,
                     density_noise_std=args.density_noise_std, log_interval=args.log_interval,
-                    rng=args.rng)
+                    rng=args.rng, graph=args.graph)
     run.model.precision = args.precision
+    run.model.train_precision = args.train_precision
     run.write_params(vars(args))
     run.fit(epochs=args.epochs, max_iterations=args.max_iterations)
     if run.rank == 0 and run.psnrs:
