@@ -90,3 +90,34 @@ def test_two_ranks_on_one_gpu(tmp_path):
     assert full.numel() == 304438
     scale = full.abs().max()
     assert (r0["flat"] - full).abs().max() <= 2e-6 * scale
+
+
+def _graph_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import trainer as T
+        dev = torch.device("cuda:0")
+        images, poses, focal = T.synthetic_scene(num_views=5, size=16, num_samples=24, device=dev)
+        run = T.Trainer(images, poses, focal, batch_size=200, learning_rate=5e-4, num_samples_per_ray=24,
+                        density_noise_std=0.5, log_interval=10 ** 9, seed=3, graph=True)
+        run.model.train_precision = "f16x3"
+        first = float(run.fit(epochs=1, max_iterations=1))
+        last = float(run.fit(epochs=40))                  # 1,024 rays per epoch: 5 batches of 100 + a tail of 12 per rank
+        params = torch.cat([p.detach().reshape(-1) for p in run.model.parameters()]).cpu()
+        torch.save(dict(first=first, last=last, params=params, graph_rays=run._graph_rays),
+                   os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_graph_replayed_training(tmp_path):
+    """Data-parallel Trainer(graph=True): backward inside the graph, all-reduce + Adam outside; the two
+    replicas must stay bitwise identical (same reduced gradients) and the fit must progress."""
+    mp.spawn(_graph_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "g0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    assert g0["graph_rays"] == 100 and g1["graph_rays"] == 100
+    assert torch.equal(g0["params"], g1["params"])
+    assert g0["last"] == g0["last"] and g0["last"] < 0.5 * g0["first"]
