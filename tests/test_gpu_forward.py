@@ -305,10 +305,11 @@ def test_many_samples_per_ray(dev):
     assert (seg[:, 0].cpu() - ref_seg)[ok].abs().max() <= 2e-4
 
 
-def test_f16x3_range_guard_and_training_stays_fp32(dev, precision):
+def test_f16x3_range_guard_and_inference_precision_leaves_training_alone(dev, precision):
     """precision='f16x3' refuses parameters outside the f16 range of its scaled operands, and does
-    not touch training: a forward that records a backward runs the fp32 kernels whatever the
-    attribute says (bitwise the same loss and gradients)."""
+    not touch training: a forward that records a backward takes its arithmetic from
+    ``train_precision`` (default fp32) whatever ``precision`` says — bitwise the same loss and
+    gradients."""
     from nerf_amd import NeRF
     if precision != "f16x3":
         pytest.skip("f16x3 only")
