@@ -168,6 +168,9 @@ inline const char* build_flags() {
 #ifdef NERF_STAGGER
            "NERF_STAGGER "
 #endif
+#if defined(NERF_PRIO_MFMA) || defined(NERF_PRIO_VALU)
+           "NERF_PRIO "
+#endif
 #ifdef NERF_BWD_STAGGER
            "NERF_BWD_STAGGER "
 #endif

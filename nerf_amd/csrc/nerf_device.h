@@ -11,6 +11,14 @@
 #include "nerf_layout.h"
 #include "nerf_common.h"
 
+// wave priorities: a wave in a VALU phase (encoding, LayerNorm, compositing) above a wave inside an
+// MFMA loop (-DNERF_PRIO_MFMA=.. / -DNERF_PRIO_VALU=.. override them for experiments)
+#ifndef NERF_PRIO_MFMA
+#define NERF_PRIO_MFMA 0
+#endif
+#ifndef NERF_PRIO_VALU
+#define NERF_PRIO_VALU 2
+#endif
 
 namespace nerf_device {
 
@@ -211,7 +219,7 @@ __device__ __forceinline__ void layer_wide(Pipe& pipe, f32x4 (&acc)[16], const f
     // compositing) wins issue arbitration against its SIMD partner's MFMA stream, finishes the
     // phase sooner and returns to feeding the matrix pipe (+0.7 % measured; MFMAs lose nothing,
     // they need one issue slot per 32 cycles).
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const f32x4* st = pipe.open_stage();
     a[0][0] = st[0];
     a[0][1] = st[64];
@@ -248,7 +256,7 @@ __device__ __forceinline__ void layer_wide(Pipe& pipe, f32x4 (&acc)[16], const f
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // Same for a short run of stages whose B operands are f32x4 values (backward, layer 5).
@@ -355,7 +363,7 @@ __device__ __forceinline__ void layer_wide_h(Pipe& pipe, f32x4 (&acc)[16], const
                                              const h8 (&blo)[KB], Hook hook = Hook()) {
     constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
     h8 ah[kSets], al[kSets];
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.template open_stage<kEntryYounger>();
 #pragma unroll
     for (int u = 0; u < kSets - 1; ++u) {
@@ -392,7 +400,7 @@ __device__ __forceinline__ void layer_wide_h(Pipe& pipe, f32x4 (&acc)[16], const
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // ---------------------------------------------------------------------------------------------

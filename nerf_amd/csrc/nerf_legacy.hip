@@ -130,7 +130,7 @@ __device__ __forceinline__ void load_bias(const float* small_l, int g, f32x4 (&a
 
 // One-tile head (256 -> <= 16 outputs): one stage = 16 quads, quad t = the A operands of k-group t.
 __device__ __forceinline__ f32x4 head_layer(LegacyPipe& pipe, f32x4 acc, const float (&act)[64]) {
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const f32x4* st = pipe.open_stage();
     f32x4 a[16];
 #pragma unroll
@@ -143,7 +143,7 @@ __device__ __forceinline__ f32x4 head_layer(LegacyPipe& pipe, f32x4 acc, const f
         acc = mfma4(a[t].z, act[4 * t + 2], acc);
         acc = mfma4(a[t].w, act[4 * t + 3], acc);
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
     return acc;
 }
 

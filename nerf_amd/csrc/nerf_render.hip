@@ -186,7 +186,7 @@ __device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x
     mom.reset();
     f32x4 a[2][2];
     f32x4 ga, be;               // gamma / beta of the tile being normalised next
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const f32x4* st = pipe.open_stage();
     a[0][0] = st[0];
     a[0][1] = st[64];
@@ -240,7 +240,7 @@ __device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x
     mom.add(out[15]);
     in[14] = out[14];
     in[15] = out[15];
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // Layer 5 (256 -> 64 padded): 4 stages, each 4 k-groups x 4 out tiles; its input is normalised
@@ -249,7 +249,7 @@ template <bool kTrain>
 __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
                                           const LazyNorm& norm) {
     normalize_tile<kTrain>(in[0], norm, 0);
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
 #pragma unroll
     for (int s = 0; s < kStagesL5; ++s) {
         const f32x4* st = pipe.open_stage();
@@ -286,7 +286,7 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
             if (t + 1 < 16) normalize_tile<kTrain>(in[t + 1], norm, t + 1);
         }
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +331,7 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
     h8 ah[kSets], al[kSets];
     f32x4 ga, be;
     h2 nh[4], nl[4];                                     // halves of the block being built
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.open_stage();
 #pragma unroll
     for (int u = 0; u < kSets - 1; ++u) {
@@ -403,7 +403,7 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
         }
     }
     mom.add(out[15]);
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
     h8 ah[kSets], al[kSets];
     f32x4 ga = norm.gam[2], be = norm.bet[2];
     h2 nh[4], nl[4];
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.open_stage();
 #pragma unroll
     for (int u = 0; u < kSets - 1; ++u) {
@@ -469,7 +469,7 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
 // ---------------------------------------------------------------------------------------------
