@@ -302,6 +302,20 @@ struct TurnHook {
     __device__ __forceinline__ void operator()(int t) const { turn(t); }
 };
 
+#ifdef NERF_EXP_STAMPS       /* diagnostic build: phase time stamps of two co-resident workgroups,
+                                scalar-only (s_memtime + s_store: no vector register is touched) */
+#define STAMP(k)                                                                                          \
+    do {                                                                                                  \
+        if (stamp_on && stamp_off < 504u) {                                                               \
+            uint64_t t_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, %2"           \
+                         : "=&s"(t_) : "s"(stamp_buf), "s"(stamp_off) : "memory");                        \
+            stamp_off += 8u;                                                                              \
+        }                                                                                                 \
+    } while (0)
+#else
+#define STAMP(k) ((void)0)
+#endif
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ba.a;
@@ -328,6 +342,18 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
         for (int i = 0; i < NERF_BWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
+#ifdef NERF_EXP_STAMPS
+    // workgroups b and b + gridDim/2 share a CU (round-robin dispatch): stamp WG 0 and its partner
+    const bool stamp_on = (blockIdx.x % (gridDim.x / 2)) == 0;
+    uint64_t* const stamp_buf = (uint64_t*)(ba.dymax + (size_t)kMaxDataGrid * 8) + ((blockIdx.x / (gridDim.x / 2)) * 4 + wave) * 64;
+    uint32_t stamp_off = 0;
+    if (stamp_on) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_nop 0\n\ts_store_dword %0, %1, %2"
+                     : "=&s"(hw) : "s"(stamp_buf), "s"(stamp_off) : "memory");
+        stamp_off = 8u;
+    }
+#endif
     float act[64];
     f32x4 acc[16];
     GammaBetaTurn turn;
@@ -349,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
                 for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
             }
 
+            STAMP(1);                                     // item start (dout loaded)
             // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -360,16 +387,20 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
+                STAMP(2);                                 // loop end = LayerNorm backward start
                 layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                     ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                STAMP(3);                                 // LayerNorm backward end = loop start
                 layer_wide<kStagesHidden>(pipe, acc, act,
                                           BwdHook{turn, ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g,
                                                   ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
+            STAMP(2);
             layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
                                 gb, turn);
+            STAMP(4);                                     // item end
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,6 +411,9 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     __syncthreads();
     for (int i = threadIdx.x; i < kGbFloats; i += 256)
         ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+#ifdef NERF_EXP_STAMPS
+    asm volatile("s_dcache_wb" ::: "memory");
+#endif
 }
 
 // timing experiments of the split-precision chain (wrong results; listed by nerf_hip_build_flags)
@@ -1309,7 +1343,11 @@ extern "C" {
 
 size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
     if (n_rays <= 0 || num_samples < 2) return 0;
+#ifdef NERF_EXP_STAMPS
+    return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float) + 8 * 64 * 8;
+#else
     return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);
+#endif
 }
 
 int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {

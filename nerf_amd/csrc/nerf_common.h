@@ -168,6 +168,9 @@ inline const char* build_flags() {
 #ifdef NERF_STAGGER
            "NERF_STAGGER "
 #endif
+#ifdef NERF_EXP_STAMPS
+           "NERF_EXP_STAMPS "
+#endif
 #if defined(NERF_PRIO_MFMA) || defined(NERF_PRIO_VALU)
            "NERF_PRIO "
 #endif
