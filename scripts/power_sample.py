@@ -20,9 +20,11 @@ def sampler():
         time.sleep(0.5)
 
 if kind == "infer":
-    from oracle import nerf_oracle as O
-    cam_o = torch.tensor([[0.0, -3.0, 2.6]], device=dev)
-    cam_r = O.look_at_pose([0.0, -3.0, 2.6]).to(dev)
+    cam = torch.tensor([[0.0, -3.0, 2.6]])
+    eye = -cam / torch.linalg.norm(cam, dim=-1, keepdim=True)
+    z = torch.tensor([[0.0, 0.0, 1.0]])
+    up = z - (z * eye).sum(-1, keepdim=True) * eye
+    cam_o, cam_r = cam.to(dev), NeRF.get_rotation_matrix(eye, up / torch.linalg.norm(up, dim=-1, keepdim=True)).to(dev)
     def work():
         with torch.no_grad():
             model.render_image(cam_o, cam_r, 800, 800, 896.0, 128)

@@ -8,7 +8,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nerf_amd import _lib
 from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE
-from oracle import nerf_oracle as O
+
+
+def look_at(camera_o):
+    """Pose looking at the origin, z up, built like the reference's get_rotation_matrix (as bench.py)."""
+    from nerf_amd import NeRF
+    cam = torch.tensor([list(camera_o)], dtype=torch.float32)
+    eye = -cam / torch.linalg.norm(cam, dim=-1, keepdim=True)
+    z = torch.tensor([[0.0, 0.0, 1.0]])
+    up = z - (z * eye).sum(-1, keepdim=True) * eye
+    up = up / torch.linalg.norm(up, dim=-1, keepdim=True)
+    return NeRF.get_rotation_matrix(eye, up)
+
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
@@ -22,7 +33,7 @@ views = []
 for ang in (0.0, 2.1, 4.2):
     cam = torch.tensor([3.5 * np.sin(ang), -3.5 * np.cos(ang), 2.0], dtype=torch.float32)
     cam = cam / cam.norm() * 4.03
-    views.append((cam[None], O.look_at_pose(cam.tolist())))
+    views.append((cam[None], look_at(cam.tolist())))
 cam_o = torch.cat([v[0] for v in views]).to(dev)
 cam_r = torch.cat([v[1] for v in views]).to(dev)
 focal = 138.88887889922103 * size / 100.0

@@ -150,6 +150,9 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(text), f
+    for f in os.listdir(os.path.join(ROOT, "scripts")):              # measurement helpers: same rule
+        if f.endswith(".py"):
+            assert not bad.search(open(os.path.join(ROOT, "scripts", f)).read()), f
     assert bad.search("from oracle import nerf_oracle as O") and bad.search("  import oracle.legacy_oracle")
 
 

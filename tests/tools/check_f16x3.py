@@ -1,6 +1,6 @@
 """f16x3 vs fp32 MLP precision: error against the oracle and frame time (GPU box)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from nerf_amd import NeRF, _lib
 from oracle import nerf_oracle as O

@@ -2,7 +2,7 @@
 oracle: which run is right, what the wrong values look like (hex), which lanes/features."""
 import os, sys, struct
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerf_amd import NeRF, _lib, workspace as W
 from oracle import nerf_oracle as O
 
