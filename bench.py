@@ -214,26 +214,38 @@ def legacy_workload_timing(dev, steps=3, warmup=1):
         with torch.no_grad():
             return model.render_image(cam_o, cam_r, IMAGE, IMAGE, focal, 2.0, 6.0, SAMPLES)
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    _lib.timing(True)
-    _lib.timing_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    kernel_ms, launches = _lib.timing_read(reset=True)
-    _lib.timing(False)
+    def timed(precision):
+        model.precision = precision
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        _lib.timing(True)
+        _lib.timing_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        kernel_ms, launches = _lib.timing_read(reset=True)
+        _lib.timing(False)
+        return dt, kernel_ms
+
     flop = IMAGE * IMAGE * SAMPLES * LEGACY_FLOP
+    dt, kernel_ms = timed("fp32")
     achieved = flop / (kernel_ms * 1e-3) / 1e12
+    dt_h, kernel_ms_h = timed("f16x3")
+    achieved_h = flop / (kernel_ms_h * 1e-3) / 1e12
     return {"workload": "legacy 8x256 network (examples/nerf.pth weights), 800x800, 128 samples/ray, "
                         "sin/cos positional encoding, fp32 MFMA; parity unpinned",
             "value": IMAGE * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "steps": steps,
             "ms_per_step": dt * 1e3, "kernel_ms": kernel_ms, "flop_per_sample": LEGACY_FLOP,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_FP32_MFMA,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_FP32_MFMA}}
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_FP32_MFMA},
+            "other_precision": {"precision": "f16x3", "value": IMAGE * IMAGE * SAMPLES / dt_h,
+                                "ms_per_step": dt_h * 1e3, "kernel_ms": kernel_ms_h,
+                                "roofline": {"bound": "mfma", "achieved": achieved_h, "peak": PEAK_TFLOPS_F16_MFMA,
+                                             "unit": "TFLOP/s", "frac": achieved_h / PEAK_TFLOPS_F16_MFMA,
+                                             "executed_frac": 3 * achieved_h / PEAK_TFLOPS_F16_MFMA}}}
 
 
 def profiled_traffic(precision):

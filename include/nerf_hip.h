@@ -204,8 +204,8 @@ typedef struct NerfHipLegacyArgs {
     /* rays (arrays or cameras), num_samples = S sample POSITIONS per ray (S network evaluations),
      * t_table [S] (+ u [n,S] for stratified sampling) or t_values [n,S], t_scale, noise [n,S],
      * density_noise_std, packed (nerf_hip_legacy_pack_weights), rgb [n,3], out_weights [n,S],
-     * out_raw [n,S,4] = density | color logits.  seg, train_workspace, out_mean/cov/t, rng_mode,
-     * precision and base_radius_sq must be 0 / NULL. */
+     * out_raw [n,S,4] = density | color logits, precision (FP32 or F16X3, as for the main network).
+     * seg, train_workspace, out_mean/cov/t, rng_mode and base_radius_sq must be 0 / NULL. */
     NerfHipRenderArgs render;
     float normalize_position;   /* positions are divided by this before encoding (notebook: 6.0) */
     float multiplier;           /* frequency f_k = multiplier * 2^k (chosen: pi)                 */

@@ -41,7 +41,23 @@ constexpr int kLegacyBlobFloats = kLegacyStages * kStageFloats;
 constexpr int kLegacySmallPerLayer = 3 * kHidden;                              // bias, gamma, beta
 constexpr int kHeadBiasFloats = 32;                                            // density [16], color [16]
 constexpr int kLegacySmallFloats = kWide * kLegacySmallPerLayer + kHeadBiasFloats;   // 7,712
-constexpr int kLegacyPackedFloats = kLegacyBlobFloats + kLegacySmallFloats;
+// Split-precision ("f16x3") image of the same network (nerf_layout.h: slab format of the main kernel's
+// f16-pair image; weights x 2^8, activations enter x 2^4): wide layer L has KB = inputs / 32 k blocks
+// (2 for layer 0, 8, or 10 with a concatenated encoding padded to two blocks) = 2 KB stages of 8 (out
+// tile, k block) pairs; a head is one stage = the 8 k blocks of its single out tile.
+__host__ __device__ constexpr int wide_blocks(int L) { return L == 0 ? 2 : ((L == 4 || L == 8) ? 10 : 8); }
+constexpr int kLegacyHStages = 4 + 3 * 16 + 20 + 3 * 16 + 1 + 20 + 16 + 1;     // 158
+constexpr int kLegacyHBlobFloats = kLegacyHStages * kStageFloats;
+constexpr int kLegacyHOffset = kLegacyBlobFloats + kLegacySmallFloats;
+constexpr int kLegacyHSmallOffset = kLegacyHOffset + kLegacyHBlobFloats;
+constexpr int kLegacyPackedFloats = kLegacyHSmallOffset + kLegacySmallFloats;
+__host__ __device__ inline int h_stage_of_layer(int L) {    // first stage of wide layer L in the f16 image
+    int s = 0;
+    for (int i = 0; i < L; ++i) s += 2 * wide_blocks(i);
+    return s + (L >= 8 ? 1 : 0);
+}
+constexpr int kHDensityStage = 4 + 3 * 16 + 20 + 3 * 16;     // 120
+constexpr int kHColorStage = kLegacyHStages - 1;
 constexpr int kLegacySmallBytes = (kLegacySmallFloats * 4 + 127) / 128 * 128;
 constexpr int kLegacyLdsBytes = kRingBytes + kLegacySmallBytes;                // 79,104 B -> 2 workgroups / CU
 
@@ -60,6 +76,7 @@ struct LegacyKernelArgs {
 };
 
 typedef WeightPipe<kLegacyStages> LegacyPipe;
+typedef WeightPipe<kLegacyHStages> LegacyHPipe;
 
 // sin(y) or cos(y) (shift) for |y| up to a few thousand rad: the half-turn reduction of
 // nerf_device.h: sin_reduced, with the cosine taken as sin(pi/2 - |r|) of the REDUCED argument
@@ -269,6 +286,206 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same launch in split-precision arithmetic (LegacyNeRF8x256.precision = "f16x3"): every fp32
+// operand of the twelve matrix products as an f16 pair, three v_mfma_f32_16x16x32_f16 per product, fp32
+// accumulation (layer_wide_h of nerf_device.h: the data gradient's loop, B operands split up front).
+// Accumulators hold 2^12 (W x + b); ReLU and LayerNorm run on them with eps * 2^24 (bit-identical
+// x_hat); gamma / beta come pre-scaled by 2^4 so the next layer's operands are already in range.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void relu_layer_norm_h(const f32x4 (&acc)[16], const float* small_l, int g,
+                                                  float (&act)[64]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
+            sum += act[4 * T + r];
+        }
+    const float mean = group_sum(sum) * (1.0f / 256.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float d = act[i] - mean;
+        sq = __builtin_fmaf(d, d, sq);
+    }
+    constexpr float kEps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) * (float)(1 << (kWScaleLog2 + kXScaleLog2));
+    const float ve = group_sum(sq) * (1.0f / 256.0f) + kEps;
+    float rstd = __builtin_amdgcn_rsqf(ve);
+    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
+    const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
+    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden + g * 64);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const f32x4 ga = gam[T], be = bet[T];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            act[4 * T + r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
+    }
+}
+
+// k block m of a 64-register activation tile set = tiles 2m, 2m + 1 -> an f16-pair B operand
+__device__ __forceinline__ void split_block(const float (&act)[64], int m, h8& hi, h8& lo) {
+    split8(f32x4{act[8 * m], act[8 * m + 1], act[8 * m + 2], act[8 * m + 3]},
+           f32x4{act[8 * m + 4], act[8 * m + 5], act[8 * m + 6], act[8 * m + 7]}, hi, lo);
+}
+
+// one-tile head: one stage = pair i = (out tile 0, k block i)
+__device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, const float (&act)[64]) {
+    h8 bh[8], bl[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    const h8* st = (const h8*)pipe.open_stage();
+    h8 ah[8], al[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        ah[m] = st[(2 * m) * 64];
+        al[m] = st[(2 * m + 1) * 64];
+    }
+    pipe.prefetch_next();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        acc = mfma_h(ah[m], bh[m], acc);
+        acc = mfma_h(ah[m], bl[m], acc);
+        acc = mfma_h(al[m], bh[m], acc);
+    }
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyKernelArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipLegacyArgs& la = ka.l;
+    const NerfHipRenderArgs& a = la.render;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int S = a.num_samples;
+    constexpr float kX = (float)(1 << kXScaleLog2), kUn = 1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2));
+
+    float* small = (float*)(smem + kRingBytes);
+    for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyHSmallOffset + i];
+    LegacyHPipe pipe;
+    pipe.init(a.packed + kLegacyHOffset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
+        int64_t local = grp * kWavesPerWg + wave;
+        const bool ray_ok = local < a.n_rays;
+        if (!ray_ok) local = a.n_rays - 1;
+        const Ray ray = load_ray(a, local);
+        const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
+        h8 dir_h[2], dir_l[2];                    // the encoded view direction as two k blocks, once per ray
+        {
+            float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
+            if (la.normalize_directions) {
+                const float inv = 1.0f / dlen;
+                dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
+            }
+            float dir_act[64];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                dir_act[q] = q < kDirPerGroup ? kX * encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
+            split_block(dir_act, 0, dir_h[0], dir_l[0]);
+            split_block(dir_act, 1, dir_h[1], dir_l[1]);
+        }
+        RayAccum racc;
+        racc.reset();
+        for (int c = 0; c < ka.chunks; ++c) {
+            const int s = c * kSamplesPerWave + j;
+            const bool ok = s < S;
+            const int sc = s < S - 1 ? s : S - 1;
+            const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
+            const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
+            h8 pos_h[2], pos_l[2];
+            {
+                float pos_act[64];
+                {
+#pragma clang fp contract(off)
+                    const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
+                                        (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
+                                        (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        pos_act[q] = q < kPosPerGroup ? kX * encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
+                }
+                split_block(pos_act, 0, pos_h[0], pos_l[0]);
+                split_block(pos_act, 1, pos_h[1], pos_l[1]);
+            }
+            f32x4 acc[16];
+            float act[64];
+            // ---- block_0 ----
+            load_bias(small, g, acc);
+            layer_wide_h<2, 0>(pipe, acc, pos_h, pos_l);
+            relu_layer_norm_h(acc, small, g, act);
+#pragma unroll 1
+            for (int L = 1; L <= 7; ++L) {
+                const float* sl = small + L * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                if (L == 4) {                     // block_1's first layer: [hidden | encoded position]
+                    h8 bh[10], bl[10];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+                    bh[8] = pos_h[0], bl[8] = pos_l[0], bh[9] = pos_h[1], bl[9] = pos_l[1];
+                    layer_wide_h<10, 0>(pipe, acc, bh, bl);
+                } else {
+                    h8 bh[8], bl[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+                    layer_wide_h<8, 0>(pipe, acc, bh, bl);
+                }
+                relu_layer_norm_h(acc, sl, g, act);
+            }
+            // ---- density head ----
+            const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
+            const f32x4 dens = head_layer_h(pipe, hb[g], act) * kUn;
+            // ---- block_2: [hidden | encoded direction] -> 256 -> 256 ----
+            {
+                const float* sl = small + 8 * kLegacySmallPerLayer;
+                load_bias(sl, g, acc);
+                {
+                    h8 bh[10], bl[10];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+                    bh[8] = dir_h[0], bl[8] = dir_l[0], bh[9] = dir_h[1], bl[9] = dir_l[1];
+                    layer_wide_h<10, 0>(pipe, acc, bh, bl);
+                }
+                relu_layer_norm_h(acc, sl, g, act);
+                const float* sl9 = small + 9 * kLegacySmallPerLayer;
+                load_bias(sl9, g, acc);
+                {
+                    h8 bh[8], bl[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+                    layer_wide_h<8, 0>(pipe, acc, bh, bl);
+                }
+                relu_layer_norm_h(acc, sl9, g, act);
+            }
+            const f32x4 col = head_layer_h(pipe, hb[4 + g], act) * kUn;
+            f32x4 out[4];
+            out[0] = f32x4{dens.x, col.x, col.y, col.z};
+            out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float w = composite_chunk<false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
+            if (ray_ok && ok && g == 0) {
+                const int64_t smp = local * S + s;
+                if (a.out_weights != nullptr) a.out_weights[smp] = w;
+                if (a.out_raw != nullptr) {
+                    a.out_raw[smp * 4 + 0] = dens.x;
+                    a.out_raw[smp * 4 + 1] = col.x;
+                    a.out_raw[smp * 4 + 2] = col.y;
+                    a.out_raw[smp * 4 + 3] = col.z;
+                }
+            }
+        }
+        store_ray(a, local, ray_ok, lane, racc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
 // parameter re-layout: the checkpoint's 44 tensors (oracle/legacy_oracle.py: state_dict_keys order)
 //   wide layer L = 0..9 (block_0 x4, block_1 x4, block_2 x2): params 4L .. 4L+3 = W, b, gamma, beta
 //   with the two heads spliced in: density W, b at 32, 33; block_2 at 34..41; color W, b at 42, 43
@@ -285,7 +502,72 @@ __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kLegacyPackedFloats) return;
     float v = 0.f;
-    if (e < kLegacyBlobFloats) {
+    if (e >= kLegacyHSmallOffset) {
+        // small image of the split-precision path: bias * 2^12, gamma * 2^4, beta * 2^4, head biases * 2^12
+        const int i = e - kLegacyHSmallOffset;
+        const float sb = (float)(1 << (kWScaleLog2 + kXScaleLog2)), sx = (float)(1 << kXScaleLog2);
+        if (i < kWide * kLegacySmallPerLayer) {
+            const int L = i / kLegacySmallPerLayer, rem = i % kLegacySmallPerLayer;
+            const int which = rem / kHidden, q = rem % kHidden;
+            const int g = q / 64, T = (q % 64) / 4, reg = q & 3;
+            v = pa.p[wide_param(L) + 1 + which][16 * T + 4 * g + reg] * (which == 0 ? sb : sx);
+        } else {
+            const int q = i - kWide * kLegacySmallPerLayer;
+            const int head = q / 16, n = q % 16;
+            if (head == 0 && n < 1) v = pa.p[33][n] * sb;
+            if (head == 1 && n < 3) v = pa.p[43][n] * sb;
+        }
+    } else if (e >= kLegacyHOffset) {
+        // f16-pair image: this float slot carries two halfs of one slab ([lane][8 halfs], 1 KiB)
+        const int eb = e - kLegacyHOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k, r = jj & 3;
+            float w = 0.f;
+            if (stage == kHDensityStage || stage == kHColorStage) {
+                // head: pair = k block, out tile 0: A[row = output][k = 16 (2 pair + (jj >> 2)) + 4 kg + r]
+                const bool color = stage == kHColorStage;
+                const int nout = color ? 3 : 1;
+                if (row < nout) w = pa.p[color ? 42 : 32][row * kHidden + 16 * (2 * pair + (jj >> 2)) + 4 * kg + r];
+            } else {
+                int L = 0, first = 0;
+                for (L = 0; L < kWide; ++L) {
+                    first = h_stage_of_layer(L);
+                    if (stage >= first && stage < first + 2 * wide_blocks(L)) break;
+                }
+                const int KB = wide_blocks(L), sl = stage - first;
+                const int half = sl / KB, m = sl % KB;
+                const int out = 16 * (8 * half + pair) + row;
+                const int tt = 2 * m + (jj >> 2);             // register tile of the B operand
+                const int K = wide_inputs(L);
+                int col = -1;
+                if (L == 0) {
+                    const int q = 4 * tt + r;
+                    if (q < kPosPerGroup) col = kPosPerGroup * kg + q;
+                } else if (tt < 16) {
+                    col = 16 * tt + 4 * kg + r;
+                } else {
+                    const int q = 4 * (tt - 16) + r;
+                    if (L == 4 && q < kPosPerGroup) col = kHidden + kPosPerGroup * kg + q;
+                    if (L == 8 && q < kDirPerGroup) col = kHidden + kDirPerGroup * kg + q;
+                }
+                if (col >= 0) w = pa.p[wide_param(L)][out * K + col];
+            }
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
+    } else if (e < kLegacyBlobFloats) {
         const int stage = e / kStageFloats;
         const int in_stage = e - stage * kStageFloats;
         const int quad = in_stage / kQuadFloats;
@@ -389,14 +671,19 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static unsigned done = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel, kLegacyLdsBytes, device, &done);
+    if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: unknown precision");
+    const bool half = a.precision == NERF_HIP_PRECISION_F16X3;
+    static unsigned done = 0, done_h = 0;
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_h_kernel, kLegacyLdsBytes, device, &done_h)
+              : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel, kLegacyLdsBytes, device, &done);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    hipLaunchKernelGGL(nerf_legacy_fwd_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    if (half) hipLaunchKernelGGL(nerf_legacy_fwd_h_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    else hipLaunchKernelGGL(nerf_legacy_fwd_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

@@ -53,6 +53,9 @@ class LegacyNeRF8x256(nn.Module):
         self._packed = None
         self._packed_key = None
         self._tables = {}
+        # arithmetic of the twelve matrix products: "fp32" = exact-fp32 MFMA, "f16x3" = every operand
+        # as an f16 pair, three f16 MFMAs per product, fp32 accumulation (as nerf_amd.model.NeRF.precision)
+        self.precision = "fp32"
 
     # pose helpers of the reference's class, unchanged (nerf/model.py:243-367)
     generate_rays = staticmethod(_GenerationC.generate_rays)
@@ -90,6 +93,19 @@ class LegacyNeRF8x256(nn.Module):
                        "nerf_hip_legacy_pack_weights")
         return self._packed
 
+    def _check_f16x3_range(self):
+        """The split-precision kernel holds 2^8 * w and 2^4 * (gamma * x_hat + beta) as f16 pairs
+        (|x_hat| < 16 for 256 features): refuse parameters outside that range instead of saturating."""
+        with torch.no_grad():
+            linears = [m for m in self.modules() if isinstance(m, nn.Linear)]
+            norms = [m for m in self.modules() if isinstance(m, nn.LayerNorm)]
+            w_dev = torch.stack([m.weight.abs().max() for m in linears]).max()
+            a_dev = torch.stack([16.0 * m.weight.abs().max() + m.bias.abs().max() for m in norms]).max()
+            w_max, act_max = (float(v) for v in torch.stack([w_dev, a_dev]).cpu())
+        if w_max * 256.0 >= 65504.0 or act_max * 16.0 >= 65504.0:
+            raise ValueError(f"nerf_amd: parameters out of range for precision='f16x3' (max |w| {w_max:.3g}, "
+                             f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
+
     def _table(self, near, far, num_samples, device):
         """Linear sample positions in [near, far] (torch.linspace on the CPU, cached on the device)."""
         key = (float(near), float(far), int(num_samples), str(device))
@@ -122,6 +138,11 @@ class LegacyNeRF8x256(nn.Module):
         r.density_noise_std = float(density_noise_std)
         r.packed, r.rgb = _lib.ptr(packed), _lib.ptr(rgb)
         r.out_raw, r.out_weights = _lib.ptr(raw), _lib.ptr(weights)
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        r.precision = _lib.PRECISIONS[self.precision]
+        if self.precision == "f16x3":
+            self._check_f16x3_range()
         args.normalize_position = self.normalize_position
         args.multiplier = self.multiplier
         args.normalize_directions = 1 if self.normalize_directions else 0

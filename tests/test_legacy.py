@@ -48,18 +48,21 @@ def test_module_tree_takes_the_checkpoint():
         model.render_rays(torch.zeros(4, 3), torch.ones(4, 3), 2.0, 6.0, 8)
 
 
-def _model(dev, params):
+def _model(dev, params, precision="fp32"):
     from nerf_amd.legacy import LegacyNeRF8x256
     model = LegacyNeRF8x256()
     model.load_state_dict(params)
+    model.precision = precision
     return model.to(dev)
 
 
 @pytest.mark.gpu
-def test_trained_checkpoint_vs_oracle():
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_trained_checkpoint_vs_oracle(precision):
+    """Both arithmetics of the kernel at the same tolerances (f16x3: f16-pair operands, fp32 results)."""
     dev = torch.device("cuda:0")
     params, g = checkpoint()
-    model = _model(dev, params)
+    model = _model(dev, params, precision)
     o, d = g["rays_o"].to(dev), g["rays_d"].to(dev)
     rgb, raw, weights = model.render_rays(o, d, 2.0, 6.0, 40, per_sample=True)
     assert (raw[..., :1].cpu() - g["density"]).abs().max() <= 2e-3 * max(1.0, float(g["density"].abs().max()))
@@ -82,14 +85,15 @@ def test_trained_checkpoint_vs_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("n_rays,num_samples", [(1, 2), (5, 17), (37, 33), (130, 64), (3, 100)])
-def test_random_weights_ragged_shapes_vs_oracle(n_rays, num_samples):
+def test_random_weights_ragged_shapes_vs_oracle(n_rays, num_samples, precision):
     dev = torch.device("cuda:0")
     params = L.init_params(seed=n_rays)
     for k in params:                                            # sharper field: densities of both signs, O(1) logits
         if k.endswith(".weight") and params[k].dim() == 2:
             params[k] = params[k] * 2.0
-    model = _model(dev, params)
+    model = _model(dev, params, precision)
     g = torch.Generator().manual_seed(100 + n_rays)
     o = torch.randn(n_rays, 3, generator=g)
     d = torch.randn(n_rays, 3, generator=g)
