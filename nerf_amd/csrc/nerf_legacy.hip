@@ -292,8 +292,10 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
 // Accumulators hold 2^12 (W x + b); ReLU and LayerNorm run on them with eps * 2^24 (bit-identical
 // x_hat); gamma / beta come pre-scaled by 2^4 so the next layer's operands are already in range.
 // ---------------------------------------------------------------------------------------------
+// (the normalised activations leave as the next layer's B operands, k block m = tiles 2m, 2m + 1)
 __device__ __forceinline__ void relu_layer_norm_h(const f32x4 (&acc)[16], const float* small_l, int g,
-                                                  float (&act)[64]) {
+                                                  h8 (&bh)[8], h8 (&bl)[8]) {
+    float act[64];
     float sum = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T)
@@ -316,11 +318,16 @@ __device__ __forceinline__ void relu_layer_norm_h(const f32x4 (&acc)[16], const 
     const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden + g * 64);
 #pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        const f32x4 ga = gam[T], be = bet[T];
+    for (int m = 0; m < 8; ++m) {
+        f32x4 y[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            act[4 * T + r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
+        for (int h = 0; h < 2; ++h) {
+            const int T = 2 * m + h;
+            const f32x4 ga = gam[T], be = bet[T];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[h][r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
+        }
+        split8(y[0], y[1], bh[m], bl[m]);
     }
 }
 
@@ -331,10 +338,7 @@ __device__ __forceinline__ void split_block(const float (&act)[64], int m, h8& h
 }
 
 // one-tile head: one stage = pair i = (out tile 0, k block i)
-__device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, const float (&act)[64]) {
-    h8 bh[8], bl[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
+__device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, const h8 (&bh)[8], const h8 (&bl)[8]) {
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.open_stage();
     h8 ah[8], al[8];
@@ -416,55 +420,39 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 split_block(pos_act, 1, pos_h[1], pos_l[1]);
             }
             f32x4 acc[16];
-            float act[64];
+            h8 bh[10], bl[10];                    // B operands: k blocks 0..7 = hidden activations, 8..9 = an encoding
             // ---- block_0 ----
             load_bias(small, g, acc);
             layer_wide_h<2, 0>(pipe, acc, pos_h, pos_l);
-            relu_layer_norm_h(acc, small, g, act);
+            relu_layer_norm_h(acc, small, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
 #pragma unroll 1
             for (int L = 1; L <= 7; ++L) {
                 const float* sl = small + L * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
                 if (L == 4) {                     // block_1's first layer: [hidden | encoded position]
-                    h8 bh[10], bl[10];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
                     bh[8] = pos_h[0], bl[8] = pos_l[0], bh[9] = pos_h[1], bl[9] = pos_l[1];
                     layer_wide_h<10, 0>(pipe, acc, bh, bl);
                 } else {
-                    h8 bh[8], bl[8];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
-                    layer_wide_h<8, 0>(pipe, acc, bh, bl);
+                    layer_wide_h<8, 0>(pipe, acc, *(h8(*)[8])bh, *(h8(*)[8])bl);
                 }
-                relu_layer_norm_h(acc, sl, g, act);
+                relu_layer_norm_h(acc, sl, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
             }
             // ---- density head ----
             const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-            const f32x4 dens = head_layer_h(pipe, hb[g], act) * kUn;
+            const f32x4 dens = head_layer_h(pipe, hb[g], *(h8(*)[8])bh, *(h8(*)[8])bl) * kUn;
             // ---- block_2: [hidden | encoded direction] -> 256 -> 256 ----
             {
                 const float* sl = small + 8 * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
-                {
-                    h8 bh[10], bl[10];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
-                    bh[8] = dir_h[0], bl[8] = dir_l[0], bh[9] = dir_h[1], bl[9] = dir_l[1];
-                    layer_wide_h<10, 0>(pipe, acc, bh, bl);
-                }
-                relu_layer_norm_h(acc, sl, g, act);
+                bh[8] = dir_h[0], bl[8] = dir_l[0], bh[9] = dir_h[1], bl[9] = dir_l[1];
+                layer_wide_h<10, 0>(pipe, acc, bh, bl);
+                relu_layer_norm_h(acc, sl, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
                 const float* sl9 = small + 9 * kLegacySmallPerLayer;
                 load_bias(sl9, g, acc);
-                {
-                    h8 bh[8], bl[8];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) split_block(act, m, bh[m], bl[m]);
-                    layer_wide_h<8, 0>(pipe, acc, bh, bl);
-                }
-                relu_layer_norm_h(acc, sl9, g, act);
+                layer_wide_h<8, 0>(pipe, acc, *(h8(*)[8])bh, *(h8(*)[8])bl);
+                relu_layer_norm_h(acc, sl9, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
             }
-            const f32x4 col = head_layer_h(pipe, hb[4 + g], act) * kUn;
+            const f32x4 col = head_layer_h(pipe, hb[4 + g], *(h8(*)[8])bh, *(h8(*)[8])bl) * kUn;
             f32x4 out[4];
             out[0] = f32x4{dens.x, col.x, col.y, col.z};
             out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
