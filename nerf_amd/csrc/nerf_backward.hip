@@ -1,19 +1,24 @@
 // Backward of the fused renderer w.r.t. the 22 parameter tensors (gfx950 only).  Replaces PyTorch
-// autograd through NeRF.render_rays (loss.backward(), train_conditional_nerf.py:133).  Three
-// launches, no atomics, bitwise reproducible:
-//   1. nerf_bwd_data_kernel  — per 16-sample chunk, last chunk of a ray first: compositing
-//      backward (model.py:438-469, :660-663) -> dL/d(out), then the data-gradient chain
-//      dX = W^T dY on fp32 MFMA with the transposed weight image streamed through LDS exactly
-//      like the forward, LayerNorm/ReLU backward in registers from the saved x_hat / 1/std.
-//      Writes dY of every layer (row order) for the weight gradients; gamma/beta gradients are
-//      row-reduced by DPP and summed per workgroup in LDS.
-//   2. nerf_wgrad_kernel     — dW_L = dY_L^T X_L as a split-K MFMA GEMM over the padded samples;
-//      operands are staged [sample][feature] fp32 tiles moved by LDS-DMA and split in registers
-//      into bf16 triples (24 significand bits, fp32 exponent range), six
-//      v_mfma_f32_32x32x16_bf16 per product with fp32 accumulation (the exact-fp32 32x32x2 form is
-//      kept behind -DNERF_WGRAD_FP32); each workgroup writes a partial slab (and the bias partial
-//      = column sums of dY).
-//   3. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
+// autograd through NeRF.render_rays (loss.backward(), train_conditional_nerf.py:133).  Four
+// launches, no float atomics, bitwise reproducible:
+//   1. nerf_composite_bwd_kernel — per ray, last chunk first: compositing backward
+//      (model.py:438-469, :660-663) -> dL/d(out) of every sample.
+//   2. nerf_bwd_data_kernel / nerf_bwd_data_h_kernel — per 16-sample chunk: the data-gradient chain
+//      dX = W^T dY with the transposed weight image streamed through LDS exactly like the forward,
+//      LayerNorm/ReLU backward in registers from the saved x_hat / 1/std.  fp32 MFMA, or (the
+//      training forward's precision = F16X3) f16 pairs with an exact per-sample power-of-two scale
+//      of dY.  Writes dY of every layer (row order) for the weight gradients; gamma/beta gradients
+//      are row-reduced by DPP and summed per workgroup in LDS; the f16 form also records the
+//      largest |dY| per layer for kernel 3.
+//   3. nerf_wgrad_kernel / nerf_wgrad_h_kernel — dW_L = dY_L^T X_L as a split-K MFMA GEMM over the
+//      padded samples: a continuous stream of 16-sample k-steps through a 4-slot LDS ring
+//      ([sample][feature] fp32 tiles moved by LDS-DMA), operands split in registers into bf16 triples
+//      (24 significand bits, fp32 exponent range; six v_mfma_f32_32x32x16_bf16 per product) or, in
+//      the split-precision mode, f16 pairs under one batch-wide power-of-two scale per layer (three
+//      v_mfma_f32_32x32x16_f16); fp32 accumulation (the exact-fp32 32x32x2 form is kept behind
+//      -DNERF_WGRAD_FP32); each workgroup writes a partial slab (and the bias partial = column
+//      sums of dY).
+//   4. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
 //      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
 #include <type_traits>
 
