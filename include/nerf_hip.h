@@ -49,10 +49,10 @@ int nerf_hip_version(void);
 /* Message for the most recent failing call on this thread ("" if none). */
 const char* nerf_hip_last_error(void);
 
-/* Experiment macros (-DNERF_ABL_* / -DNERF_EXP_* / ...) this library was compiled with, space
- * separated; "" for the product build.  Most of them produce WRONG results on purpose (timing
- * ablations), so the Python loader refuses a non-empty answer unless the library was selected
- * explicitly with NERF_HIP_LIB.  No reference counterpart (build hygiene). */
+/* Name of the experiment this library was built as (-DNERF_HIP_EXPERIMENT=name: a throw-away
+ * variant for timing work), "" for the product build.  The Python loader refuses a non-empty answer
+ * unless the library was selected explicitly with NERF_HIP_LIB.  No reference counterpart (build
+ * hygiene). */
 const char* nerf_hip_build_flags(void);
 
 /* Size in bytes of the packed parameter image consumed by the render kernels. */

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NERF_HIP_LIB selects another build of the same ABI (kernel experiments: scripts/ablate.py)
+# NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
 ABI_VERSION = 3
 NUM_PARAM_TENSORS = 22
@@ -116,8 +116,8 @@ def lib():
     flags = handle.nerf_hip_build_flags().decode().split()
     if flags and not os.environ.get("NERF_HIP_LIB"):
         raise RuntimeError(
-            f"{LIB_PATH} was compiled with experiment macros {flags} (timing ablations: wrong results "
-            "on purpose); rebuild the product library, or select an experimental build explicitly "
+            f"{LIB_PATH} was compiled as an experiment {flags} (-DNERF_HIP_EXPERIMENT: not the product "
+            "kernels); rebuild the product library, or select an experimental build explicitly "
             "with NERF_HIP_LIB=<path>")
     _lib = handle
     return _lib

@@ -15,8 +15,7 @@
 //      ([sample][feature] fp32 tiles moved by LDS-DMA), operands split in registers into bf16 triples
 //      (24 significand bits, fp32 exponent range; six v_mfma_f32_32x32x16_bf16 per product) or, in
 //      the split-precision mode, f16 pairs under one batch-wide power-of-two scale per layer (three
-//      v_mfma_f32_32x32x16_f16); fp32 accumulation (the exact-fp32 32x32x2 form is kept behind
-//      -DNERF_WGRAD_FP32); each workgroup writes a partial slab (and the bias partial = column
+//      v_mfma_f32_32x32x16_f16); fp32 accumulation (the exact-fp32 32x32x2 form of round 1 is in the history); each workgroup writes a partial slab (and the bias partial = column
 //      sums of dY).
 //   4. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
 //      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
@@ -307,20 +306,6 @@ struct TurnHook {
     __device__ __forceinline__ void operator()(int t) const { turn(t); }
 };
 
-#ifdef NERF_EXP_STAMPS       /* diagnostic build: phase time stamps of two co-resident workgroups,
-                                scalar-only (s_memtime + s_store: no vector register is touched) */
-#define STAMP(k)                                                                                          \
-    do {                                                                                                  \
-        if (stamp_on && stamp_off < 504u) {                                                               \
-            uint64_t t_;                                                                                  \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, %2"           \
-                         : "=&s"(t_) : "s"(stamp_buf), "s"(stamp_off) : "memory");                        \
-            stamp_off += 8u;                                                                              \
-        }                                                                                                 \
-    } while (0)
-#else
-#define STAMP(k) ((void)0)
-#endif
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ba.a;
@@ -342,23 +327,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     pipe.issue();
     __syncthreads();
 
-#ifdef NERF_BWD_STAGGER
-    if (blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < NERF_BWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#ifdef NERF_EXP_STAMPS
-    // workgroups b and b + gridDim/2 share a CU (round-robin dispatch): stamp WG 0 and its partner
-    const bool stamp_on = (blockIdx.x % (gridDim.x / 2)) == 0;
-    uint64_t* const stamp_buf = (uint64_t*)(ba.dymax + (size_t)kMaxDataGrid * 8) + ((blockIdx.x / (gridDim.x / 2)) * 4 + wave) * 64;
-    uint32_t stamp_off = 0;
-    if (stamp_on) {
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_nop 0\n\ts_store_dword %0, %1, %2"
-                     : "=&s"(hw) : "s"(stamp_buf), "s"(stamp_off) : "memory");
-        stamp_off = 8u;
-    }
-#endif
     float act[64];
     f32x4 acc[16];
     GammaBetaTurn turn;
@@ -379,8 +347,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
 #pragma unroll
                 for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
             }
-
-            STAMP(1);                                     // item start (dout loaded)
             // ---- layer 5: dX = W5^T dOut (4 stages of the transposed image) ----
 #pragma unroll
             for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -392,20 +358,16 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
-                STAMP(2);                                 // loop end = LayerNorm backward start
                 layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                     ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-                STAMP(3);                                 // LayerNorm backward end = loop start
                 layer_wide<kStagesHidden>(pipe, acc, act,
                                           BwdHook{turn, ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g,
                                                   ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
-            STAMP(2);
             layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
                                 gb, turn);
-            STAMP(4);                                     // item end
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,28 +378,11 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     __syncthreads();
     for (int i = threadIdx.x; i < kGbFloats; i += 256)
         ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
-#ifdef NERF_EXP_STAMPS
-    asm volatile("s_dcache_wb" ::: "memory");
-#endif
 }
 
-// timing experiments of the split-precision chain (wrong results; listed by nerf_hip_build_flags)
-#ifdef NERF_EXP_BWD_NOXHAT
-#define BWD_XHAT(p) (f32x4{0.5f, -0.25f, 0.125f, 1.0f})
-constexpr int kYoungerL5 = 0, kYoungerHidden = 16;
-#else
-#define BWD_XHAT(p) (*(const f32x4*)(p))
-#ifdef NERF_EXP_BWD_NOLN
-constexpr int kYoungerL5 = 17, kYoungerHidden = 17;
-#else
+// vector-memory operations issued between the DMA of a loop's stage 1 and its first hand-overs: the 17
+// x_hat / 1/std loads (layer 5's loop), or the 16 dY saves of the LayerNorm backward + those 17 loads
 constexpr int kYoungerL5 = 17, kYoungerHidden = 33;
-#endif
-#endif
-#ifdef NERF_EXP_BWD_NOMFMA
-#define BWD_MFMA(x) ((void)0)
-#else
-#define BWD_MFMA(x) x
-#endif
 // The same chain in split-precision arithmetic (see row_scale above).
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -462,11 +407,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     pipe.issue();
     __syncthreads();
 
-#ifdef NERF_BWD_STAGGER
-    if (blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < NERF_BWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     float act[64];
     f32x4 acc[16];
     GammaBetaTurn turn;
@@ -493,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
             // x_hat / 1/std of layer 4 first: 17 loads that fly under the 4 stages of layer 5
             const float* xrow = ws + ba.L.xhat[4] + sp * kHidden + 4 * g;
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = BWD_XHAT(xrow + T * 16);
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow + T * 16);
             rstd = ws[ba.L.rstd[4] + sp];
             float unscale;
             {
@@ -508,26 +448,19 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                 split8(dout[2] * sc, dout[3] * sc, bh[1], bl[1]);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-                BWD_MFMA((layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn})));
+                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});
             }
 #pragma unroll 1
             for (int L = 4; L >= 0; --L) {
-#ifdef NERF_EXP_BWD_NOLN
-#pragma unroll
-                for (int T = 0; T < 16; ++T)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) act[4 * T + r] = acc[T][r] * unscale + xh[T][r] * rstd;
-#else
                 layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                           ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
                                           turn, unscale);
-#endif
                 if (L == 0) break;                // dy[0] feeds only the weight gradient
                 // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
                 // all of them younger than the two stages this layer's loop opens first
                 const float* xrow_n = ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g;
 #pragma unroll
-                for (int T = 0; T < 16; ++T) xh[T] = BWD_XHAT(xrow_n + T * 16);
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);
                 rstd = ws[ba.L.rstd[L - 1] + sp];
                 // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
                 // workgroup's maximum) the weight-gradient kernel's
@@ -547,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                 }
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-                BWD_MFMA((layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, TurnHook{turn})));
+                layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, TurnHook{turn});
             }
         }
     }
@@ -582,143 +515,8 @@ typedef WgradShape<kHidden, kEncIn, 2, 3> ShapeL0;        // waves: out tiles 2w
 typedef WgradShape<kHidden, kHidden, 4, 4> ShapeHid;       // waves 2x2: 4x4 tiles each
 typedef WgradShape<kOutPad, kHidden, 2, 2> ShapeL5;        // waves: both out tiles, in tiles 2w..2w+1
 
-template <class Sh>
-__device__ __forceinline__ void wgrad_issue_piece(const float* dy, const float* x, int64_t sample0,
-                                                  char* buf, int wave, int lane, int i) {
-    {
-        const int piece = wave * Sh::kPiecesPerWave + i;
-        const int byte = piece * 1024;
-        const char* src = byte < Sh::kDyBytes
-                              ? (const char*)(dy + sample0 * Sh::kOutW) + byte
-                              : (const char*)(x + sample0 * Sh::kInW) + (byte - Sh::kDyBytes);
-#ifndef NERF_EXP_WGRAD_NODMA     /* timing experiment only */
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(buf + byte), 16, 0, 0);
-#endif
-    }
-}
-template <class Sh>
-__device__ __forceinline__ void wgrad_issue(const float* dy, const float* x, int64_t sample0,
-                                            char* buf, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < Sh::kPiecesPerWave; ++i) wgrad_issue_piece<Sh>(dy, x, sample0, buf, wave, lane, i);
-}
-
-// `x` rows are the layer's input: the encoded features (layer 0, kAffine false) or the saved x_hat
-// of the previous layer, turned into relu(gamma * x_hat + beta) as the operands are read from LDS.
-template <class Sh, bool kAffine>
-__device__ __forceinline__ void wgrad_body(const BwdArgs& ba, char* smem, const float* dy, const float* x,
-                                           const float* small_prev, int w_off, int b_off, int split) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    int out0, in0;                                // first 32-wide tile of this wave
-    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
-    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
-    else { out0 = 0; in0 = 2 * wave; }
-
-    // gamma / beta of this lane's input features (feature f sits at [(f % 16) / 4][f / 16][f % 4]
-    // of the packed small image)
-    float ga[Sh::kTi], be[Sh::kTi];
-#pragma unroll
-    for (int b = 0; b < Sh::kTi; ++b) {
-        const int f = 32 * (in0 + b) + (lane & 31);
-        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
-        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
-        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
-    }
-    auto input = [&](float v, int b) {
-        return kAffine ? __builtin_fmaxf(__builtin_fmaf(v, ga[b], be[b]), 0.f) : v;
-    };
-
-    f32x16 acc[Sh::kTo][Sh::kTi];
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bias_sum = 0.f;
-
-    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
-    int64_t tile_end = tile_begin + ba.tiles_per_split;
-    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
-    const int64_t nt = tile_end > tile_begin ? tile_end - tile_begin : 0;
-
-    if (nt > 0) wgrad_issue<Sh>(dy, x, tile_begin * kKs, smem, wave, lane);
-    for (int64_t k = 0; k < nt; ++k) {
-        // The next tile's LDS-DMA pieces are issued ONE PER K-STEP inside this tile's MFMA loop (one
-        // wave per SIMD here: a burst of 16 back-to-back DMA issues would idle the matrix pipe for
-        // ~1,000 of the tile's 16,384 cycles).  So at this point only this tile's pieces can be in
-        // flight: vmcnt(0).
-        char* cur = smem + (k & 1) * Sh::kTileBytes;
-        char* nxt_buf = smem + ((k + 1) & 1) * Sh::kTileBytes;
-        const bool more = k + 1 < nt;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const float* dyt = (const float*)cur;
-        const float* xt = (const float*)(cur + Sh::kDyBytes);
-        const int i = lane & 31, kk = lane >> 5;
-        // operands of k-step s+1 are read right after the first MFMA of k-step s (two register
-        // sets), so an LDS read always has a whole k-step of MFMAs to land
-        float af[2][Sh::kTo], bf[2][Sh::kTi];
-#pragma unroll
-        for (int a = 0; a < Sh::kTo; ++a) af[0][a] = dyt[kk * Sh::kOutW + 32 * (out0 + a) + i];
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b) bf[0][b] = xt[kk * Sh::kInW + 32 * (in0 + b) + i];
-#pragma unroll
-        for (int step = 0; step < kKs / 2; ++step) {
-            const int cur = step & 1, nxt = cur ^ 1;
-            // affine + ReLU at USE time: applied at load time it would pull the LDS wait up to the
-            // reads and undo their one-k-step prefetch
-            float bv[Sh::kTi];
-#pragma unroll
-            for (int b = 0; b < Sh::kTi; ++b) bv[b] = input(bf[cur][b], b);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bv[0], acc[0][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (step < Sh::kPiecesPerWave && more)
-                wgrad_issue_piece<Sh>(dy, x, (tile_begin + k + 1) * kKs, nxt_buf, wave, lane, step);
-            if (step + 1 < kKs / 2) {
-                const int srow = 2 * (step + 1) + kk;
-#pragma unroll
-                for (int a = 0; a < Sh::kTo; ++a) af[nxt][a] = dyt[srow * Sh::kOutW + 32 * (out0 + a) + i];
-#pragma unroll
-                for (int b = 0; b < Sh::kTi; ++b) bf[nxt][b] = xt[srow * Sh::kInW + 32 * (in0 + b) + i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-                for (int b = 0; b < Sh::kTi; ++b)
-                    if (a + b > 0)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bv[b], acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if ((int)threadIdx.x < Sh::kOutW) {       // bias gradient: column sums of dY
-#pragma unroll 8
-            for (int srow = 0; srow < kKs; ++srow) bias_sum += dyt[srow * Sh::kOutW + threadIdx.x];
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
-    const int col = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r];
-            }
-    if ((int)threadIdx.x < Sh::kOutW) slab[b_off + threadIdx.x] = bias_sum;
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
+// The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
 // bits, by truncation, and bf16 has fp32's exponent range, so gradients of any magnitude are
 // represented exactly — an f16 pair would need a data-dependent scale for dY) and six
 // v_mfma_f32_32x32x16_bf16 per product: hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi, fp32
@@ -799,7 +597,6 @@ __device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
     const uint64_t sbase = ((uint64_t)hi << 32) | lo;
     const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
     uint32_t m0_saved;
-#ifndef NERF_EXP_WGRAD_NODMA     /* timing experiment only */
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
@@ -812,7 +609,6 @@ __device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
         : "=&s"(m0_saved)
         : "v"(lane * 16), "s"(d), "s"(sbase), "n"(N)
         : "memory");
-#endif
 }
 
 // DMA instructions every wave issues per k-step (the same count on every wave: the hand-over's
@@ -958,12 +754,6 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
             const int na = a + 1 < Sh::kTo ? a + 1 : 0;
             const float* asrc = a + 1 < Sh::kTo ? dyt : dyn;
             float raw[1 + kBPerSlot][8];
-#ifdef NERF_EXP_WGRAD_NOLDS      /* timing experiment only: operands are not read */
-#pragma unroll
-            for (int q = 0; q < 1 + kBPerSlot; ++q)
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) raw[q][jj] = ga[0] * (float)(jj + q);
-#else
             const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
             if (next_a) {
 #pragma unroll
@@ -977,14 +767,12 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                     for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[jj * Sh::kInW + 32 * b];
                 }
             }
-#endif
             unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
             u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
             h2 qh[1 + kBPerSlot][4], ql[1 + kBPerSlot][4];   // f16 form: pair p of the operand, hi / lo
             const Operand& ac = at[a & 1];
             Operand& an = at[(a & 1) ^ 1];
             __builtin_amdgcn_sched_barrier(0);
-#ifndef NERF_WGRAD_PINNED
             if constexpr (kF16) {
                 // f16 form: the slot's 3 kTi MFMAs and its conversions (4 dependent levels per value
                 // pair: scale, pkrtz, residual, pkrtz) handed to the scheduler as ONE region with the
@@ -1030,7 +818,6 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                 __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
-#endif
 #pragma unroll
             for (int m = 0; m < kMfmas; ++m) {
                 const int b = m / kPerProduct, tt = m % kPerProduct;
@@ -1082,12 +869,6 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
                             }
                         }
                     } else {
-#ifdef NERF_EXP_WGRAD_NOCONV     /* timing experiment only: raw bits instead of the bf16 triple */
-                    if (w < 8) {
-                        th[op][w] = tm[op][w] = tl[op][w] = __builtin_bit_cast(unsigned, raw[op][w]);
-                        continue;
-                    }
-#endif
                     if (w < 8) {
                         float val = raw[op][w];
                         asm volatile("" : "+v"(val));
@@ -1200,11 +981,6 @@ __device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, c
     }
 }
 
-#if defined(NERF_WGRAD_FP32)    /* the exact-fp32 32x32x2 GEMM (kept as the comparison build) */
-#define WGRAD_BODY wgrad_body
-#else
-#define WGRAD_BODY wgrad_body_ring
-#endif
 
 // All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
 // layer-0 / layer-5 jobs fill the tail instead of running half-empty launches of their own.
@@ -1214,14 +990,14 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;       // [layer][bias | gamma | beta][256]
     if (job < 4) {                                // layers 1..4: input = LayerNorm+ReLU of layer job
-        WGRAD_BODY<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+        wgrad_body_ring<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
                                    ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
                                    small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
                                    kSlabB + (job + 1) * kHidden, split);
     } else if (job == 4) {                        // layer 0: input = encoded features
-        WGRAD_BODY<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
+        wgrad_body_ring<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
     } else {                                      // layer 5: input = LayerNorm+ReLU of layer 4
-        WGRAD_BODY<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+        wgrad_body_ring<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
                                   kSlabW5, kSlabB + 5 * kHidden, split);
     }
 }
@@ -1348,11 +1124,7 @@ extern "C" {
 
 size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
     if (n_rays <= 0 || num_samples < 2) return 0;
-#ifdef NERF_EXP_STAMPS
-    return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float) + 8 * 64 * 8;
-#else
     return ((size_t)kMaxSplits * kSlabFloats + (size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);
-#endif
 }
 
 int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
@@ -1420,16 +1192,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
                        dim3(256), 0, st, ba);
     if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
     else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
-#ifdef NERF_EXP_WGRAD_HID_ONLY   /* timing experiment: hidden layers only (wrong gradients) */
-    const int wgrad_jobs = 4;
-#else
     const int wgrad_jobs = 6;
-#endif
-#if defined(NERF_WGRAD_FP32) || defined(NERF_WGRAD_BF16_ONLY)
-    const bool wgrad_half = false;
-#else
     const bool wgrad_half = half;
-#endif
     if (wgrad_half)
         hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
     else

@@ -109,84 +109,18 @@ struct Timing {
     }
 };
 
-// Experiment macros compiled into this build, space separated ("" for the product build).  Most of
-// them make the kernels compute WRONG results on purpose (timing ablations: scripts/ablate.py);
-// the loader (nerf_amd/_lib.py) refuses such a library unless it was asked for by path.
+// Name of the experiment this library was built as ("" for the product build).  The product sources
+// carry no experiment switches (settled ones live on the `experiments-r02` branch and under
+// scripts/probes/); a throw-away variant built with -DNERF_HIP_EXPERIMENT=name says so here, and the
+// loader (nerf_amd/_lib.py) refuses such a library unless it was asked for by path.
+#define NERF_HIP_STR2(x) #x
+#define NERF_HIP_STR(x) NERF_HIP_STR2(x)
 inline const char* build_flags() {
-    return ""
-#ifdef NERF_ABL_ENCODE
-           "NERF_ABL_ENCODE "
+#ifdef NERF_HIP_EXPERIMENT
+    return NERF_HIP_STR(NERF_HIP_EXPERIMENT);
+#else
+    return "";
 #endif
-#ifdef NERF_ABL_COMP
-           "NERF_ABL_COMP "
-#endif
-#ifdef NERF_ABL_LN
-           "NERF_ABL_LN "
-#endif
-#ifdef NERF_ABL_SPLIT
-           "NERF_ABL_SPLIT "
-#endif
-#ifdef NERF_EXP_NOWAIT
-           "NERF_EXP_NOWAIT "
-#endif
-#ifdef NERF_EXP_NOBARRIER
-           "NERF_EXP_NOBARRIER "
-#endif
-#ifdef NERF_EXP_NODMA
-           "NERF_EXP_NODMA "
-#endif
-#ifdef NERF_EXP_NOLDS
-           "NERF_EXP_NOLDS "
-#endif
-#ifdef NERF_EXP_PACKNORM
-           "NERF_EXP_PACKNORM "
-#endif
-#ifdef NERF_EXP_NOPACKMOM
-           "NERF_EXP_NOPACKMOM "
-#endif
-#ifdef NERF_EXP_WGRAD_NODMA
-           "NERF_EXP_WGRAD_NODMA "
-#endif
-#ifdef NERF_EXP_WGRAD_HID_ONLY
-           "NERF_EXP_WGRAD_HID_ONLY "
-#endif
-#ifdef NERF_WGRAD_FP32
-           "NERF_WGRAD_FP32 "
-#endif
-#ifdef NERF_WGRAD_PINNED
-           "NERF_WGRAD_PINNED "
-#endif
-#ifdef NERF_WGRAD_BF16_ONLY
-           "NERF_WGRAD_BF16_ONLY "
-#endif
-#ifdef NERF_EXP_WGRAD_NOLDS
-           "NERF_EXP_WGRAD_NOLDS "
-#endif
-#ifdef NERF_EXP_WGRAD_NOCONV
-           "NERF_EXP_WGRAD_NOCONV "
-#endif
-#ifdef NERF_STAGGER
-           "NERF_STAGGER "
-#endif
-#ifdef NERF_EXP_STAMPS
-           "NERF_EXP_STAMPS "
-#endif
-#if defined(NERF_PRIO_MFMA) || defined(NERF_PRIO_VALU)
-           "NERF_PRIO "
-#endif
-#ifdef NERF_BWD_STAGGER
-           "NERF_BWD_STAGGER "
-#endif
-#ifdef NERF_EXP_BWD_NOXHAT
-           "NERF_EXP_BWD_NOXHAT "
-#endif
-#ifdef NERF_EXP_BWD_NOLN
-           "NERF_EXP_BWD_NOLN "
-#endif
-#ifdef NERF_EXP_BWD_NOMFMA
-           "NERF_EXP_BWD_NOMFMA "
-#endif
-        ;
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes

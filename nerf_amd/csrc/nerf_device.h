@@ -12,13 +12,9 @@
 #include "nerf_common.h"
 
 // wave priorities: a wave in a VALU phase (encoding, LayerNorm, compositing) above a wave inside an
-// MFMA loop (-DNERF_PRIO_MFMA=.. / -DNERF_PRIO_VALU=.. override them for experiments)
-#ifndef NERF_PRIO_MFMA
+// MFMA loop (the other orders were measured and lose: DESIGN.md section 7)
 #define NERF_PRIO_MFMA 0
-#endif
-#ifndef NERF_PRIO_VALU
 #define NERF_PRIO_VALU 2
-#endif
 
 namespace nerf_device {
 
@@ -171,13 +167,9 @@ struct WeightPipe {
     // read before it has landed.
     template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
-#ifndef NERF_EXP_NOWAIT      /* timing experiments only (wrong results) */
         static_assert(kYounger >= 0 && 4 + kYounger <= 63, "vmcnt immediate");
         asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(4 + kYounger) : "memory");
-#endif
-#ifndef NERF_EXP_NOBARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
         read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
@@ -185,9 +177,7 @@ struct WeightPipe {
     }
     __device__ __forceinline__ void prefetch_next() {
         asm volatile("" ::: "memory");
-#ifndef NERF_EXP_NODMA
         issue();
-#endif
     }
 };
 
@@ -309,11 +299,6 @@ __device__ __forceinline__ float residual(float x, const h2& pair) {
 __device__ __forceinline__ void split4(const f32x4& v, h2& hi0, h2& hi1, h2& lo0, h2& lo1) {
     hi0 = pack_rtz(v.x, v.y);
     hi1 = pack_rtz(v.z, v.w);
-#ifdef NERF_ABL_SPLIT        /* timing experiment only */
-    lo0 = hi0;
-    lo1 = hi1;
-    return;
-#endif
     lo0 = pack_rtz(residual<0>(v.x, hi0), residual<1>(v.y, hi0));
     lo1 = pack_rtz(residual<0>(v.z, hi1), residual<1>(v.w, hi1));
 }
@@ -614,15 +599,9 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         const float scale = base * (float)(1 << (p / 3));
         const float y = gs.mean[p % 3] * scale;
         const float yv = gs.cov[p % 3] * (scale * scale);
-#ifdef NERF_ABL_ENCODE      /* timing experiment only: no transcendental */
-        const float damp = 1.0f - 0.001f * yv;
-        act[p] = damp * (y * 1e-6f);
-        act[12 + p] = damp * ((y + half_pi) * 1e-6f);
-#else
         const float damp = expf(-0.5f * yv);
         act[p] = damp * sin_reduced(y);
         act[12 + p] = damp * sin_reduced(y + half_pi);
-#endif
     }
 }
 
@@ -689,11 +668,7 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
     acc.rgb1 += row_sum(cg);
     acc.rgb2 += row_sum(cb);
 
-#ifdef NERF_ABL_COMP         /* timing experiment only: no segmentation compositing */
-    if (false) {
-#else
     if (a.seg != nullptr) {
-#endif
         // log_softmax over the 50 class logits of this sample
         float m = -__builtin_inff();
 #pragma unroll

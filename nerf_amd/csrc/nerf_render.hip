@@ -61,9 +61,6 @@ struct Moments {
     __device__ __forceinline__ float sum() const { return s; }
     __device__ __forceinline__ float sum_sq() const { return q; }
     __device__ __forceinline__ void add(const f32x4& v) {
-#ifdef NERF_ABL_LN
-        return;
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s += v[r];
@@ -82,9 +79,6 @@ struct MomentsPk {
     __device__ __forceinline__ float sum() const { return s.x + s.y; }
     __device__ __forceinline__ float sum_sq() const { return q.x + q.y; }
     __device__ __forceinline__ void add(const f32x4& v) {
-#ifdef NERF_ABL_LN
-        return;
-#endif
         const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
         s += a;
         q = a * a + q;
@@ -97,11 +91,6 @@ template <bool kTrain, bool kPacked = false>
 __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T, const f32x4& ga,
                                                const f32x4& be) {
     f32x4 xh;
-#ifdef NERF_ABL_LN           /* timing experiment only: ReLU without the normalisation */
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaxf(x[r], 0.f);
-    return;
-#endif
     if (kPacked) {
         xh = x * n.rstd + n.shift;              // packed fp32 fmas, two values per instruction
         x = __builtin_elementwise_max(xh * ga + be, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -297,23 +286,10 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
 // Image and scalings: nerf_layout.h.  A k block m = register tiles 2m, 2m+1 of the input; its
 // B operands are built (normalise lazily like layer_fused, then split) one stage ahead.
 // ---------------------------------------------------------------------------------------------
-#ifdef NERF_EXP_NOLDS         /* timing experiment only: operands are not re-read */
-#define LDSRD(x, keep) (keep)
-#else
-#define LDSRD(x, keep) (x)
-#endif
 // packed fp32 in the normalisation costs aligned register pairs: at this register pressure it
 // spills inside the layer loops (150 ms per frame against 136), so only the moments are packed
-#ifdef NERF_EXP_PACKNORM
-constexpr bool kPackNorm = true;
-#else
 constexpr bool kPackNorm = false;
-#endif
-#ifdef NERF_EXP_NOPACKMOM
-typedef Moments HMoments;
-#else
 typedef MomentsPk HMoments;
-#endif
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
 // built (normalise tile by tile, then split) during stage (0, m).
@@ -361,8 +337,8 @@ __device__ __forceinline__ void layer_fused_h(FwdPipe& pipe, f32x4 (&in)[16], f3
                     else if (mine || prev) st = (const h8*)pipe.template open_stage<2>();
                     else st = (const h8*)pipe.open_stage();
                 }
-                ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
-                al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
+                ah[pset] = st[(2 * ip) * 64];
+                al[pset] = st[(2 * ip + 1) * 64];
                 if (ip == 0) pipe.prefetch_next();
             }
             if (kNormIn && build_next && (i == 0 || i == 2)) {   // a unit ahead of their use
@@ -440,8 +416,8 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
             if (U + kSets - 1 < kUnits) {
                 const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
                 if (ip == 0) st = (const h8*)pipe.open_stage();
-                ah[pset] = LDSRD(st[(2 * ip) * 64], ah[set]);
-                al[pset] = LDSRD(st[(2 * ip + 1) * 64], al[set]);
+                ah[pset] = st[(2 * ip) * 64];
+                al[pset] = st[(2 * ip + 1) * 64];
                 if (ip == 0) pipe.prefetch_next();
             }
             if (q == 1 && m + 1 < 8) {
@@ -500,15 +476,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
-#ifdef NERF_STAGGER
-    // The two workgroups of a CU run the same program; started together they stay in phase and
-    // their VALU phases (encoding, LayerNorm, compositing) coincide instead of hiding under the
-    // partner's MFMAs.  Delay the second half of the grid (the second resident block per CU under
-    // round-robin dispatch) by about half a chunk, once.
-    if (blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < NERF_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators
     float* const ws = a.train_workspace;

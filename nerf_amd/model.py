@@ -297,10 +297,25 @@ class NeRF(nn.Module):
                              f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
         self._f16x3_checked = key
 
-    def check_split_precision_range(self):
-        """Force the f16 range check of the parameters now (raises ValueError when they left it)."""
+    def _forget_range_check(self):
         self._f16x3_checked = None
         self._f16x3_calls = -1
+
+    def load_state_dict(self, *args, **kwargs):
+        """As nn.Module.load_state_dict; the next split-precision launch (inference or training)
+        re-checks the f16 range of the new parameters instead of waiting for its 64-launch period."""
+        out = super().load_state_dict(*args, **kwargs)
+        self._forget_range_check()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)         # .to() / .cuda() / .float(): new storages
+        self._forget_range_check()
+        return out
+
+    def check_split_precision_range(self):
+        """Force the f16 range check of the parameters now (raises ValueError when they left it)."""
+        self._forget_range_check()
         self._check_f16x3_range(training=False)
 
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,

@@ -64,6 +64,26 @@ def load_scene(path, device):
     return images, poses, focal
 
 
+def load_pickled_scene(path, device, camera_focal_length, camera_ccd_width):
+    """The reference script's data file (train_conditional_nerf.py:70-87): a pickled dict with
+    ``images`` [V,H,W,3], ``poses`` [V,6] (camera position | viewing direction) and ``states``.
+    Focal length in pixels = W * focal_mm / ccd_mm (:78-80); a pose becomes [R | t] with R from the
+    viewing direction (:86 — ``direction_to_rotation_matrix`` no longer exists in nerf/model.py; the
+    stated choice of nerf_amd.compat is used).  ``states`` are read and dropped: the generation-C
+    network ignores them (nerf/model.py:596-598).  Only unpickle files you trust."""
+    import pickle
+    from .compat import LegacyNeRF
+    with open(path, "rb") as f:
+        blob = pickle.load(f)
+    images = torch.as_tensor(np.asarray(blob["images"]), dtype=torch.float32)
+    raw = torch.as_tensor(np.asarray(blob["poses"]), dtype=torch.float32)
+    focal = float(images.shape[2]) * (float(camera_focal_length) / float(camera_ccd_width))
+    poses = torch.eye(4).repeat(raw.shape[0], 1, 1)
+    poses[:, :3, :3] = LegacyNeRF.direction_to_rotation_matrix(raw[:, 3:])
+    poses[:, :3, 3] = raw[:, :3]
+    return images.to(device), poses.to(device), focal
+
+
 class Trainer:
     def __init__(self, images, poses, focal_length, logging_dir=None, batch_size=1024,
                  learning_rate=1e-4, num_samples_per_ray=64, density_noise_std=1.0, log_interval=1000,
@@ -102,6 +122,9 @@ class Trainer:
         self._graph = None
         self._graph_rays = -1
         self._eager_steps = 0
+        self._stale_grads = False
+        begin, end = parallel.shard_items(batch_size, self.rank, self.world)
+        self._full_share = end - begin                    # rays of a full global batch that land on this rank
         if self.use_graph:
             if rng != "torch":
                 raise ValueError("graph=True needs rng='torch': the in-kernel Philox offset is a launch "
@@ -146,8 +169,12 @@ class Trainer:
         stream the capture will use (autograd's accumulation nodes must live there), step 5 is captured
         and from then on every full-size batch is a copy into the static inputs + one replay."""
         n = batch["rays_o"].shape[0]
-        if self._graph is not None and n != self._graph_rays:
-            return None                                   # tail batch of an epoch: eager
+        # Only this rank's FULL-batch share is warmed up, captured and replayed: a short batch (the
+        # tail of an epoch, an uneven shard) runs eagerly and consumes no warm-up step, so the capture
+        # can never freeze a tail size and then refuse every full batch for the rest of the run.
+        if n != self._full_share:
+            self._stale_grads = True                      # the eager step re-points p.grad
+            return None
         if self._graph is None and self._eager_steps < 5:
             self._eager_steps += 1
             if self._eager_steps <= 3:
@@ -176,9 +203,12 @@ class Trainer:
         for k, t in self._static.items():
             t.copy_(batch[k])
         self._graph.replay()
+        if self._stale_grads:                             # an eager tail step replaced them: p.grad must
+            for p, g in zip(self.model.parameters(), self._static_grads):     # show what the replay wrote
+                p.grad = g
+            self.model.last_flat_grad = self._static_flat
+            self._stale_grads = False
         if self.distributed:
-            for p, g in zip(self.model.parameters(), self._static_grads):
-                p.grad = g                                # an eager tail step may have replaced them
             self.reduce(self._static_flat, n / max(int(batch.get("global_n", n * self.world)), 1))
             self.optimizer.step()
         if self.model.train_precision == "f16x3" and self.iteration % 64 == 0:

@@ -14,7 +14,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nerf_amd import NeRF, _lib, workspace as W
+from nerf_amd import NeRF, _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import workspace_mirror as W
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10

@@ -2,7 +2,7 @@
 * the emitted ISA obeys the inline-asm hazard rules of scripts/isa_hazards.py (hipcc inserts no wait
   states inside asm statements, so the kernels may only touch registers there that a compiler-visible
   instruction wrote last) — and the scanner does catch a violation when shown one;
-* a library compiled with a wrong-result experiment macro is refused by the default loader;
+* a library compiled as an experiment (-DNERF_HIP_EXPERIMENT=...) is refused by the default loader;
 * the Python mirror of the training workspace layout matches the library's."""
 import importlib.util
 import os
@@ -62,6 +62,43 @@ _Zkernel:
     assert haz.scan(str(good)) == []
 
 
+def test_scanner_flags_an_overcounted_handover_wait(tmp_path):
+    """R6: `s_waitcnt vmcnt(4 + k)` in asm claims k compiler-emitted vector-memory ops sit between the
+    DMA of the stage being opened and the wait; with fewer, the youngest 4 + k reach into that DMA."""
+    haz = _scanner()
+    dma = "\t;;#ASMSTART\n" + "\tglobal_load_lds_dwordx4 v1, s[4:5]\n" * 4 + "\t;;#ASMEND\n"
+    stores = "\tglobal_store_dwordx4 v[2:3], v[4:7], off\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(%d) lgkmcnt(0)\n\t;;#ASMEND\n"
+    body = "_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n" + dma + stores * 2 + dma
+    ok, bad = tmp_path / "ok.s", tmp_path / "bad.s"
+    ok.write_text(body + wait % 6)                 # 2 stores + the next stage's 4 pieces may fly
+    bad.write_text(body + wait % 7)                # one more: a piece of the opened stage may fly
+    assert haz.scan(str(ok)) == []
+    assert [h[3] for h in haz.scan(str(bad))] == ["R6"]
+    pure = tmp_path / "pure.s"                     # DMA-only waits (the weight gradient's ring) are by construction
+    pure.write_text("_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n" + dma + dma + wait % 8)
+    assert haz.scan(str(pure)) == []
+
+
+def test_build_refuses_a_library_with_a_hazard(tmp_path, monkeypatch):
+    """build() scans the assembly it just produced and raises instead of linking (the rules
+    must hold for whatever hipcc builds the library, not only for the one the tests ran under)."""
+    from nerf_amd import build as nerf_build, isa_scan
+    monkeypatch.setattr(isa_scan, "scan", lambda path: [("k", 1, "v_pk_mul_f32 ...", "R5", "planted")])
+    with pytest.raises(nerf_build.IsaHazard, match="R5"):
+        nerf_build.build(out=str(tmp_path / "lib_hazard.so"), defines=("NERF_HIP_EXPERIMENT=hazard_probe",))
+    assert not os.path.exists(tmp_path / "lib_hazard.so")
+
+
+def test_stamp_tracks_flags_and_sources(tmp_path, monkeypatch):
+    from nerf_amd import build as nerf_build
+    a = nerf_build.stamp()
+    assert a == nerf_build.stamp() and a != nerf_build.stamp(defines=("X=1",))
+    monkeypatch.setattr(nerf_build, "CODEGEN_FLAGS", ["-O2", "-std=c++17"])
+    assert nerf_build.stamp() != a                 # a library built with other flags is not "up to date"
+    assert not nerf_build.up_to_date()
+
+
 def test_kernels_obey_the_inline_asm_hazard_rules(tmp_path):
     haz = _scanner()
     for name in sorted(f for f in os.listdir(haz.CSRC) if f.endswith(".hip")):
@@ -74,7 +111,7 @@ def test_kernels_obey_the_inline_asm_hazard_rules(tmp_path):
 def test_default_loader_refuses_an_experiment_build(tmp_path):
     from nerf_amd import build as nerf_build
     out = str(tmp_path / "libnerf_hip_exp.so")
-    nerf_build.build(out=out, defines=("NERF_EXP_NOBARRIER",))
+    nerf_build.build(out=out, defines=("NERF_HIP_EXPERIMENT=probe_build",))
     code = ("import nerf_amd._lib as L, sys\n"
             f"L.LIB_PATH = {out!r}\n"
             "try:\n    L.lib()\nexcept RuntimeError as e:\n    print('REFUSED', e); sys.exit(0)\n"
@@ -82,14 +119,15 @@ def test_default_loader_refuses_an_experiment_build(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT)
     env.pop("NERF_HIP_LIB", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-    assert r.returncode == 0 and "REFUSED" in r.stdout and "NERF_EXP_NOBARRIER" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "probe_build" in r.stdout, r.stdout + r.stderr
     env["NERF_HIP_LIB"] = out                       # asked for by path: allowed (scripts/ablate.py)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-    assert "LOADED ['NERF_EXP_NOBARRIER']" in r.stdout, r.stdout + r.stderr
+    assert "LOADED ['probe_build']" in r.stdout, r.stdout + r.stderr
 
 
 def test_workspace_mirror_matches_the_library():
-    from nerf_amd import _lib, build as nerf_build, workspace as W
+    from nerf_amd import _lib, build as nerf_build
+    import workspace_mirror as W
     nerf_build.build()
     lib = _lib.lib()
     assert _lib.build_flags() == []

@@ -59,7 +59,7 @@ def test_fenceposts_vs_reference_fixture(dev):
 def test_saved_stage_tensors_vs_oracle(dev, train_precision, scale):
     """What the training forward saves, read back from the workspace: h against the reference's
     fixture, x_hat / 1/std of every layer against the oracle's LayerNorm internals."""
-    from nerf_amd import workspace as W
+    import workspace_mirror as W
     g = load_golden("g1_stages" if scale == 1.0 else "g2_stages_x3")
     params = golden_params(scale)
     model = make_model(dev, scale)

@@ -3,7 +3,9 @@ oracle: which run is right, what the wrong values look like (hex), which lanes/f
 import os, sys, struct
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from nerf_amd import NeRF, _lib, workspace as W
+from nerf_amd import NeRF, _lib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import workspace_mirror as W
 from oracle import nerf_oracle as O
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"

@@ -2,8 +2,12 @@
 the generation-C renderer.  Single GPU: ``python train_nerf_amd.py --data scene.npz``; data
 parallel: ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1
 train_nerf_amd.py ...`` (one process per GPU, RCCL all-reduce of the 1.2 MB gradient per step).
-``--data synthetic`` trains against views of a synthetic teacher field (the tiny_nerf Lego file
-of the reference's notebook is not redistributable here)."""
+Flag names AND defaults are the reference's.  ``--data`` takes the reference's pickle (a dict with
+``images`` [V,H,W,3], ``poses`` [V,6] = position | viewing direction, ``states``; focal length in
+pixels = W * camera-focal-length / camera-ccd-width, train_conditional_nerf.py:70-87), an ``.npz`` in
+the tiny_nerf layout of the notebook (images, poses [V,4,4], focal), or the word ``synthetic``: views
+of a synthetic teacher field rendered by the renderer itself (the reference's data files are not in
+its repository)."""
 import argparse
 import os
 
@@ -14,13 +18,14 @@ from nerf_amd import trainer as T
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser("Train a NeRF model with the MI355X renderer")
-    ap.add_argument("--logging-dir", type=str, default="./")
-    ap.add_argument("--data", type=str, default="synthetic")
-    ap.add_argument("--epochs", type=int, default=30)
-    ap.add_argument("--camera-focal-length", type=float, default=35.0)
-    ap.add_argument("--camera-ccd-width", type=float, default=32.0)
-    ap.add_argument("--batch-size", type=int, default=4096)
-    ap.add_argument("--normalize-position", type=float, default=16.0)      # accepted, unused (gen. B)
+    # the reference's thirteen flags with its defaults (train_conditional_nerf.py:22-47)
+    ap.add_argument("--logging-dir", type=str, default="experiment")
+    ap.add_argument("--data", type=str, default="examples/data_for_nerf.pkl")
+    ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--camera-focal-length", type=float, default=50.0)
+    ap.add_argument("--camera-ccd-width", type=float, default=36.0)
+    ap.add_argument("--batch-size", type=int, default=1024)
+    ap.add_argument("--normalize-position", type=float, default=20.0)      # accepted, unused (gen. B)
     ap.add_argument("--learning-rate", type=float, default=0.0001)
     ap.add_argument("--near-plane", type=float, default=0.0)               # accepted, unused (gen. B)
     ap.add_argument("--far-plane", type=float, default=20.0)               # accepted, unused (gen. B)
@@ -48,8 +53,11 @@ if __name__ == "__main__":
 
     if args.data == "synthetic":
         images, poses, focal = T.synthetic_scene(device=device)
-    else:
+    elif args.data.endswith(".npz"):
         images, poses, focal = T.load_scene(args.data, device)
+    else:
+        images, poses, focal = T.load_pickled_scene(args.data, device, args.camera_focal_length,
+                                                    args.camera_ccd_width)
     run = T.Trainer(images, poses, focal, logging_dir=args.logging_dir, batch_size=args.batch_size,
                     learning_rate=args.learning_rate, num_samples_per_ray=args.num_samples_per_ray,
                     density_noise_std=args.density_noise_std, log_interval=args.log_interval,
