@@ -79,28 +79,82 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(rows=32):
-    """Oracle render of `rows` image rows of the bench frame on the host cores."""
+def physical_cores():
+    """Physical cores this process may run on: distinct (socket, core) pairs of /proc/cpuinfo among the
+    logical CPUs of its affinity mask (SMT siblings share a pair)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    pairs, cpu, phys = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key = key.strip()
+                if key == "processor":
+                    cpu, phys = int(val), None
+                elif key == "physical id":
+                    phys = int(val)
+                elif key == "core id" and cpu in allowed:
+                    pairs.add((phys, int(val)))
+    except (OSError, ValueError):
+        pass
+    return len(pairs) or len(allowed)
+
+
+def cpu_quota():
+    """CPUs the container's cgroup grants (cpu.max), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline_run(threads, budget_s, max_rows=32):
+    """Oracle render of up to `max_rows` image rows of the bench frame on `threads` host threads,
+    stopped after `budget_s` seconds (the sample actually rendered is reported)."""
     from oracle import nerf_oracle as O
-    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     params = O.init_params(seed=0)
     cfg = dict(O.default_config(), focal_length=FOCAL)
     cam_o, cam_r = look_at(CAMERA)
     rays_o, rays_d = O.image_rays(cam_o, cam_r, IMAGE, IMAGE, FOCAL)
-    r0 = (IMAGE - rows) // 2
-    sl = slice(r0 * IMAGE, (r0 + rows) * IMAGE)
+    r0 = (IMAGE - max_rows) // 2
+    sl = slice(r0 * IMAGE, (r0 + max_rows) * IMAGE)
     o, d = rays_o[sl], rays_d[sl]
+    done = 0
     with torch.no_grad():
         O.render_rays(params, cfg, o[:1024], d[:1024], SAMPLES)          # warm-up
         t0 = time.perf_counter()
         for a, b in zip(torch.split(o, 1024), torch.split(d, 1024)):
             O.render_rays(params, cfg, a, b, SAMPLES)
+            done += a.shape[0]
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
-    return {"value": rows * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "cores": threads,
-            "kind": "port", "cpu": cpu_model(), "host_cpus": os.cpu_count(),
-            "sample": f"{rows} rows x {IMAGE} px of the same 800x800x128 frame, chunks of 1024 rays, "
-                      f"{dt:.1f} s, torch {torch.__version__} CPU ops"}
+    return done * SAMPLES / dt, done, dt
+
+
+def cpu_baseline():
+    """The oracle on this box's host cores, twice: on min(16, CPUs) threads (the CPU share a one-GPU
+    slot of the pool is sized for) and on one thread per PHYSICAL core of the affinity mask
+    (BASELINE.md section 4).  `value` / `cores` are the better of the two; both are reported."""
+    logical = os.cpu_count() or 1
+    runs = []
+    for threads, budget in ((min(logical, 16), 12.0), (physical_cores(), 10.0)):
+        if any(r["cores"] == threads for r in runs):
+            continue
+        value, rays, dt = cpu_baseline_run(threads, budget)
+        runs.append({"cores": threads, "value": value, "rays": rays, "seconds": round(dt, 1)})
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "ray-samples/s", "cores": best["cores"],
+            "kind": "port", "cpu": cpu_model(), "host_cpus": logical, "physical_cores": physical_cores(),
+            "cgroup_cpu_quota": cpu_quota(), "runs": runs,
+            "sample": f"{best['rays']} rays (whole 1024-ray chunks of the middle rows) of the same 800x800x128 "
+                      f"frame, {best['seconds']} s, torch {torch.__version__} CPU ops, oracle/nerf_oracle.py"}
 
 
 def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32"):
@@ -248,6 +302,71 @@ def legacy_workload_timing(dev, steps=3, warmup=1):
                                              "executed_frac": 3 * achieved_h / PEAK_TFLOPS_F16_MFMA}}}
 
 
+def baseline_configs(dev):
+    """The other BASELINE.json configurations and the weights-x3 point of SURVEY.md section 8(d), fp32
+    arithmetic, a few steps each, so that the driver's record carries them (one GPU):
+      C2 100x100x64 frame; C3 400x400, 64 coarse + 128 fine (hierarchical: coarse render, inverse-CDF
+      resample, fine render of the sorted union); C4 800x800x192 whole and one of its eight 100-row
+      shards; the headline frame with every Linear weight x3 (sharper densities: same cost by design).
+    TFLOP/s = evaluated samples x 601,088 / wall time per step (synchronised)."""
+    from nerf_amd import NeRF, _lib
+    cam_o, cam_r = look_at(CAMERA)
+    cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+
+    def timed(fn, steps, warmup=1):
+        with torch.no_grad():
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize(dev)
+            _lib.timing(True)
+            _lib.timing_read(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+            kernel_ms, launches = _lib.timing_read(reset=True)
+            _lib.timing(False)
+        return dt, kernel_ms, launches // steps
+
+    def entry(workload, dt, nominal, evaluated, steps, kernel_ms, launches):
+        tf = evaluated * FLOP_PER_SAMPLE / dt / 1e12
+        return {"workload": workload, "steps": steps, "ms_per_step": dt * 1e3, "ray_samples_per_s": nominal / dt,
+                "evaluated_samples": evaluated, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TFLOPS_FP32_MFMA,
+                "render_launches_per_step": launches, "avg_render_kernel_ms": kernel_ms}
+
+    def model_for(focal, scale=1.0):
+        torch.manual_seed(0)
+        m = NeRF(focal_length=focal)
+        if scale != 1.0:
+            with torch.no_grad():
+                for slot in (0, 3, 6, 9, 12, 15):
+                    m.prediction_heads[slot].weight.mul_(scale)
+        return m.to(dev)
+
+    out = {}
+    m = model_for(112.0)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, 100, 100, 112.0, 64), steps=20, warmup=3)
+    out["C2"] = entry("100x100 frame, 64 samples/ray, one launch", dt, 100 * 100 * 64, 100 * 100 * 63, 20, k, n)
+    m = model_for(448.0)
+    dt, k, n = timed(lambda: m.render_image_hierarchical(cam_o, cam_r, 400, 400, 448.0, 64, 128), steps=3)
+    out["C3"] = entry("400x400 frame, 64 coarse + 128 fine samples/ray (coarse render, inverse-CDF resample, "
+                      "fine render of the 192-fencepost union); parity unpinned (no reference code)",
+                      dt, 400 * 400 * (64 + 192), 400 * 400 * (63 + 191), 3, k, n)
+    m = model_for(FOCAL)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192), steps=3)
+    out["C4"] = entry("800x800 frame, 192 samples/ray, one GPU", dt, IMAGE * IMAGE * 192, IMAGE * IMAGE * 191, 3, k, n)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192, row_begin=300, row_end=400), steps=5)
+    out["C4_shard"] = entry("rows 300..399 of the 800x800x192 frame: the share of one of 8 GPUs (no collective)",
+                            dt, 100 * IMAGE * 192, 100 * IMAGE * 191, 5, k, n)
+    m = model_for(FOCAL, scale=3.0)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=3)
+    out["headline_weights_x3"] = entry("the headline 800x800x128 frame with every Linear weight x3 (early "
+                                       "saturation: the kernel has no early-out, cost must not change)",
+                                       dt, IMAGE * IMAGE * SAMPLES, IMAGE * IMAGE * (SAMPLES - 1), 3, k, n)
+    return out
+
+
 def profiled_traffic(precision):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this
     same command (profiles/*_pmc_summary.json, the newest one of this precision; FETCH_SIZE/WRITE_SIZE
@@ -294,10 +413,10 @@ def roofline(precision, rays, kernel_ms, launches, with_traffic):
 
 
 def shard_rows(rank, world):
-    """Row block of rank `rank` when `world` GPUs split one frame (blocks differ by <= 1 row)."""
-    base, extra = divmod(IMAGE, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    """Row block of rank `rank` when `world` GPUs split the bench frame: the product's partition
+    (nerf_amd.parallel.shard_rows; blocks differ by at most one row and cover the frame exactly)."""
+    from nerf_amd.parallel import shard_rows as product_shard_rows
+    return product_shard_rows(IMAGE, rank, world)
 
 
 def main():
@@ -308,6 +427,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default): the GPUs split the rows of one frame; weak: one frame per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="N > 1: if RCCL cannot initialise, rendezvous over gloo instead of failing "
+                         "(the line then says rendezvous_backend gloo: no RCCL credit)")
     ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "fp32"))
     args = ap.parse_args()
 
@@ -322,8 +444,12 @@ def main():
         try:                                      # RCCL over xGMI; only barriers + one scalar reduce use it
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             backend = "nccl"
-        except Exception as exc:                  # keep the measurement alive if RCCL cannot come up
-            print(f"[bench] nccl init failed ({exc}); falling back to gloo for the barriers", file=sys.stderr)
+        except Exception as exc:
+            if not args.allow_gloo:               # a multi-GPU line without RCCL is not the measurement asked for
+                print(f"[bench] RCCL (backend nccl) failed to initialise: {exc}\n[bench] refusing to measure "
+                      "without it; pass --allow-gloo to rendezvous over gloo instead", file=sys.stderr)
+                raise
+            print(f"[bench] nccl init failed ({exc}); --allow-gloo: barriers over gloo", file=sys.stderr)
             dist.init_process_group("gloo")
             backend = "gloo"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -437,6 +563,7 @@ def main():
             line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
             line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
+            line["configs"] = baseline_configs(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if distributed:

@@ -580,33 +580,38 @@ class NeRF(nn.Module):
                               device=device)
         seg_out = torch.empty(batch, rows, image_w, self.segmentation_outputs, dtype=torch.float32,
                               device=device)
-        for b in range(batch):
-            begin = (b * image_h + row_begin) * image_w
-            n_rays = rows * image_w
-            if not stochastic or self.rng == "philox":
-                # one launch per frame, written straight into the output block.  (On the
-                # deterministic path the reference still draws a randn per chunk that it then
-                # multiplies by 0, model.py:652-654; that dead draw is not reproduced here.)
-                mode = 0
-                if stochastic:
-                    mode = (1 if randomly_sample else 0) | (2 if density_noise_std != 0.0 else 0)
-                self._launch(n_rays, num_samples, device, cameras=cameras, ray_begin=begin,
+        n_rays = rows * image_w
+        if not stochastic or self.rng == "philox":
+            # one launch per frame, written straight into the output block.  (On the deterministic
+            # path the reference still draws a randn per chunk that it then multiplies by 0,
+            # model.py:652-654; that dead draw is not reproduced here.)
+            mode = 0
+            if stochastic:
+                mode = (1 if randomly_sample else 0) | (2 if density_noise_std != 0.0 else 0)
+            for b in range(batch):
+                self._launch(n_rays, num_samples, device, cameras=cameras,
+                             ray_begin=(b * image_h + row_begin) * image_w,
                              density_noise_std=density_noise_std, rng_mode=mode,
                              rgb=rgb_out[b].reshape(n_rays, -1), seg=seg_out[b].reshape(n_rays, -1))
-                continue
-            # stochastic with torch draws: chunk so the draw tensors stay small, same draw order
-            # per chunk as the reference's loop (model.py:757-761)
-            flat_rgb = rgb_out[b].reshape(n_rays, -1)
-            flat_seg = seg_out[b].reshape(n_rays, -1)
-            step = max(int(max_chunk_size), 1)
-            for lo in range(0, n_rays, step):
-                n = min(step, n_rays - lo)
+            return rgb_out, seg_out
+        # Stochastic with torch draws: the reference flattens ALL B*H*W rays and splits that list into
+        # chunks of max_chunk_size — across frame boundaries — drawing rand [n,S] then randn [n,S-1,1]
+        # per chunk (model.py:750-761, :432, :652).  Same chunks, same draw order here; the kernel takes
+        # a chunk that straddles two frames as it is (global ray id -> frame, row, column).  A row block
+        # (the sharding extension, no reference counterpart) is chunked frame by frame.
+        step = max(int(max_chunk_size), 1)
+        if rows == image_h:
+            spans = [(0, batch * n_rays, rgb_out.reshape(batch * n_rays, -1), seg_out.reshape(batch * n_rays, -1))]
+        else:
+            spans = [((b * image_h + row_begin) * image_w, n_rays, rgb_out[b].reshape(n_rays, -1),
+                      seg_out[b].reshape(n_rays, -1)) for b in range(batch)]
+        for begin, count, flat_rgb, flat_seg in spans:
+            for lo in range(0, count, step):
+                n = min(step, count - lo)
                 u, noise, mode = self._draws(n, num_samples, device, randomly_sample, density_noise_std)
                 u = None if u is None else u.contiguous()
                 noise = None if noise is None else noise.reshape(n, num_samples - 1).contiguous()
-                rgb, seg, _, _, _ = self._launch(n, num_samples, device, cameras=cameras,
-                                                 ray_begin=begin + lo, u=u, noise=noise,
-                                                 density_noise_std=density_noise_std, rng_mode=mode)
-                flat_rgb[lo:lo + n] = rgb
-                flat_seg[lo:lo + n] = seg
+                self._launch(n, num_samples, device, cameras=cameras, ray_begin=begin + lo, u=u, noise=noise,
+                             density_noise_std=density_noise_std, rng_mode=mode,
+                             rgb=flat_rgb[lo:lo + n], seg=flat_seg[lo:lo + n])
         return rgb_out, seg_out

@@ -155,6 +155,7 @@ class Trainer:
         n, dev = o.shape[0], o.device
         u = torch.rand(n, self.num_samples, dtype=torch.float32, device=dev)           # graph-safe default
         noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32, device=dev)   # generator
+        self.last_draws = (u, noise)                      # (static tensors of the graph once captured)
         pixels, _ = self.model.render_rays(o, d, self.num_samples, randomly_sample=True,
                                            density_noise_std=self.density_noise_std, u=u,
                                            noise=noise if self.density_noise_std != 0.0 else None)
@@ -222,12 +223,15 @@ class Trainer:
                 return loss
         n = batch["rays_o"].shape[0]
         u = noise = None
-        if self.model.rng == "torch" and self.distributed:
-            # same draws a single process would make (rand, then randn), from this rank's generator
+        if self.model.rng == "torch":
+            # the reference's draws in the reference's order (rand, then randn: nerf/model.py:432, :652):
+            # from this rank's own generator when data-parallel, else from torch's default one
+            gen = self.draws if self.distributed else None
             u = torch.rand(n, self.num_samples, dtype=torch.float32, device=batch["rays_o"].device,
-                           generator=self.draws)
+                           generator=gen)
             noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32,
-                                device=batch["rays_o"].device, generator=self.draws)
+                                device=batch["rays_o"].device, generator=gen)
+        self.last_draws = (u, noise)                      # what this step rendered with (None: in-kernel Philox)
         pixels, _ = self.model.render_rays(batch["rays_o"], batch["rays_d"], self.num_samples,
                                            randomly_sample=True,
                                            density_noise_std=self.density_noise_std, u=u, noise=noise)

@@ -45,5 +45,16 @@ def test_defaults_are_the_reference_arithmetic_and_the_one_frame_partition(monke
         blocks = [bench.shard_rows(r, world) for r in range(world)]
         assert blocks[0][0] == 0 and blocks[-1][1] == bench.IMAGE
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    # one partition for the product and the bench: same blocks, and the per-rank ray counts the
+    # line reports (`rays_per_gpu`) add up to the frame for every N the driver runs
+    from nerf_amd import parallel
+    for world in (1, 2, 4, 8):
+        blocks = [bench.shard_rows(r, world) for r in range(world)]
+        assert blocks == [parallel.shard_rows(bench.IMAGE, r, world) for r in range(world)]
+        rays = [(e - b) * bench.IMAGE for b, e in blocks]
+        assert sum(rays) == bench.IMAGE * bench.IMAGE and max(rays) - min(rays) <= bench.IMAGE
+        assert rays[0] == bench.IMAGE * bench.IMAGE // world
+    assert "--allow-gloo" in src and "refusing to measure" in src      # N > 1 without RCCL fails loudly
     assert bench.PRECISIONS["fp32"]["dtype"] == "f32"
+    assert bench.physical_cores() >= 1
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()

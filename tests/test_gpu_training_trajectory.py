@@ -13,7 +13,10 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def test_forty_steps_track_the_cpu_reference_port():
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+def test_forty_steps_track_the_cpu_reference_port(train_precision):
+    """Both training arithmetics (fp32 MFMA; f16 pairs in forward, data and weight gradient) against the
+    SAME CPU run of the reference's ops: same bounds."""
     from nerf_amd import NeRF
     from nerf_amd import trainer as T
     dev = torch.device("cuda:0")
@@ -28,6 +31,7 @@ def test_forty_steps_track_the_cpu_reference_port():
     model = NeRF(focal_length=focal)
     model.load_state_dict(params0)
     model = model.to(dev)
+    model.train_precision = train_precision
     opt = torch.optim.Adam(model.parameters(), lr=lr)
 
     ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params0.items()}
@@ -66,7 +70,7 @@ def test_forty_steps_track_the_cpu_reference_port():
                                        cam_r.cpu(), 16, 16, focal, S)
     truth = images[-1:].cpu()
     psnr_gpu, psnr_cpu = float(O.psnr(render.cpu(), truth)), float(O.psnr(ref_render, truth))
-    print(f"held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port {psnr_cpu:.4f} dB; "
+    print(f"[{train_precision}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port {psnr_cpu:.4f} dB; "
           f"max loss deviation {float((gl - cl).abs().max()):.2e}")
     assert abs(psnr_gpu - psnr_cpu) <= 0.01
 
@@ -79,3 +83,56 @@ def test_forty_steps_track_the_cpu_reference_port():
     print(f"held-out PSNR, f16x3 render of the same parameters: {psnr_h:.4f} dB")
     assert abs(psnr_h - psnr_cpu) <= 0.01
     assert (render_h - render).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+def test_graph_replayed_trainer_tracks_the_cpu_reference_port(train_precision):
+    """The path the small-batch step time is quoted on: nerf_amd.trainer.Trainer(graph=True) — three
+    eager steps, two on the capture stream, then every step ONE HIP-graph replay (draws from torch's
+    graph-safe generator, forward, loss, backward, fused capturable Adam).  The oracle's CPU run sees the
+    same rays, targets and the draws each step actually used (Trainer.last_draws: after a replay, the
+    graph's own static tensors) — loss trajectory and held-out PSNR to the same bounds as the eager loop."""
+    from nerf_amd import NeRF
+    from nerf_amd import trainer as T
+    dev = torch.device("cuda:0")
+    steps, batch, S, lr = 40, 256, 32, 5e-4
+    images, poses, focal = T.synthetic_scene(num_views=6, size=16, num_samples=32, device=dev, seed=3)
+    cfg = dict(O.default_config(), focal_length=focal)
+    params0 = golden_params(1.0)
+    model = NeRF(focal_length=focal)
+    model.load_state_dict(params0)
+    model = model.to(dev)
+    model.train_precision = train_precision
+    run = T.Trainer(images, poses, focal, batch_size=batch, learning_rate=lr, num_samples_per_ray=S,
+                    density_noise_std=1.0, log_interval=10 ** 9, model=model, seed=11, graph=True)
+    ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params0.items()}
+    ref_opt = torch.optim.Adam([ref[k] for k in ref if k.startswith("prediction")], lr=lr)
+    gen = torch.Generator().manual_seed(5)
+    gpu_losses, cpu_losses = [], []
+    for step in range(steps):
+        idx = torch.randint(0, len(run.dataset), (batch,), generator=gen)
+        b = run.dataset.gather(idx.to(dev))
+        run.iteration += 1
+        loss = run.train_step(b)
+        u, noise = (t.detach().cpu().clone() for t in run.last_draws)
+        gpu_losses.append(float(loss))
+        ref_loss = O.training_loss(ref, cfg, b["rays_o"].cpu(), b["rays_d"].cpu(), S, b["pixels"].cpu(),
+                                   u, noise, 1.0)
+        ref_opt.zero_grad()
+        ref_loss.backward()
+        ref_opt.step()
+        cpu_losses.append(float(ref_loss.detach()))
+    assert run._graph is not None and run._graph_rays == batch          # steps 5.. were replays
+    gl, cl = torch.tensor(gpu_losses), torch.tensor(cpu_losses)
+    assert cl[-1] < 0.5 * cl[0]
+    assert ((gl - cl).abs() <= 2e-3 * cl + 1e-7).all(), (gl - cl).abs().max()
+    cam_o, cam_r = poses[-1:, :3, 3].contiguous(), poses[-1:, :3, :3].contiguous()
+    with torch.no_grad():
+        render, _ = model.render_image(cam_o, cam_r, 16, 16, focal, S)
+        ref_render, _ = O.render_image({k: v.detach() for k, v in ref.items()}, cfg, cam_o.cpu(),
+                                       cam_r.cpu(), 16, 16, focal, S)
+    truth = images[-1:].cpu()
+    psnr_gpu, psnr_cpu = float(O.psnr(render.cpu(), truth)), float(O.psnr(ref_render, truth))
+    print(f"[graph, {train_precision}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port "
+          f"{psnr_cpu:.4f} dB; max loss deviation {float((gl - cl).abs().max()):.2e}")
+    assert abs(psnr_gpu - psnr_cpu) <= 0.01
