@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 3
+#define NERF_HIP_ABI_VERSION 4
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -204,8 +204,9 @@ typedef struct NerfHipLegacyArgs {
     /* rays (arrays or cameras), num_samples = S sample POSITIONS per ray (S network evaluations),
      * t_table [S] (+ u [n,S] for stratified sampling) or t_values [n,S], t_scale, noise [n,S],
      * density_noise_std, packed (nerf_hip_legacy_pack_weights), rgb [n,3], out_weights [n,S],
-     * out_raw [n,S,4] = density | color logits, precision (FP32 or F16X3, as for the main network).
-     * seg, train_workspace, out_mean/cov/t, rng_mode and base_radius_sq must be 0 / NULL. */
+     * out_raw [n,S,4] = density | color logits, precision (FP32 or F16X3, as for the main network),
+     * train_workspace (training forward, FP32 only; see below).
+     * seg, out_mean/cov/t, rng_mode and base_radius_sq must be 0 / NULL. */
     NerfHipRenderArgs render;
     float normalize_position;   /* positions are divided by this before encoding (notebook: 6.0) */
     float multiplier;           /* frequency f_k = multiplier * 2^k (chosen: pi)                 */
@@ -215,6 +216,26 @@ typedef struct NerfHipLegacyArgs {
 size_t nerf_hip_legacy_packed_bytes(void);
 int nerf_hip_legacy_pack_weights(const float* const* params, float* packed, void* stream);
 int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream);
+
+/* Training of the legacy network — what the notebook's loop does through PyTorch autograd
+ * (examples/example.ipynb cell 8: render_rays(...); ((pixels - target) ** 2).mean().backward(); Adam).
+ * A forward with render.train_workspace set (nerf_hip_legacy_train_workspace_bytes() bytes; fp32 arithmetic)
+ * also saves what the backward needs; nerf_hip_legacy_render_backward then writes the flat gradient:
+ * nerf_hip_legacy_grad_elements() = 638,468 floats, the 44 tensors in the pack routine's order, each in its
+ * PyTorch layout.  `fwd` must be the argument block of that training forward.  Rays are not differentiated. */
+#define NERF_HIP_LEGACY_GRAD_ELEMENTS 638468
+size_t nerf_hip_legacy_train_workspace_bytes(int64_t n_rays, int32_t num_samples);
+size_t nerf_hip_legacy_grad_elements(void);
+
+typedef struct NerfHipLegacyBackwardArgs {
+    NerfHipLegacyArgs fwd;
+    const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
+    float* grad;                /* [nerf_hip_legacy_grad_elements()] written (not accumulated) */
+    float* scratch;             /* nerf_hip_legacy_backward_scratch_bytes() bytes          */
+} NerfHipLegacyBackwardArgs;
+
+size_t nerf_hip_legacy_backward_scratch_bytes(int64_t n_rays, int32_t num_samples);
+int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void* stream);
 
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -66,6 +66,11 @@ class LegacyArgs(ctypes.Structure):
                 ("multiplier", ctypes.c_float), ("normalize_directions", ctypes.c_int32)]
 
 
+class LegacyBackwardArgs(ctypes.Structure):
+    """Mirror of NerfHipLegacyBackwardArgs (include/nerf_hip.h)."""
+    _fields_ = [("fwd", LegacyArgs), ("d_rgb", _f32p), ("grad", _f32p), ("scratch", _f32p)]
+
+
 NUM_LEGACY_PARAM_TENSORS = 44
 _lib = None
 
@@ -105,6 +110,13 @@ def lib():
                                                     ctypes.c_void_p]
     handle.nerf_hip_legacy_render_forward.restype = ctypes.c_int
     handle.nerf_hip_legacy_render_forward.argtypes = [ctypes.POINTER(LegacyArgs), ctypes.c_void_p]
+    handle.nerf_hip_legacy_train_workspace_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_legacy_train_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    handle.nerf_hip_legacy_grad_elements.restype = ctypes.c_size_t
+    handle.nerf_hip_legacy_backward_scratch_bytes.restype = ctypes.c_size_t
+    handle.nerf_hip_legacy_backward_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    handle.nerf_hip_legacy_render_backward.restype = ctypes.c_int
+    handle.nerf_hip_legacy_render_backward.argtypes = [ctypes.POINTER(LegacyBackwardArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -127,7 +139,9 @@ EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "n
            "nerf_hip_pack_weights", "nerf_hip_render_forward", "nerf_hip_train_workspace_bytes",
            "nerf_hip_grad_elements", "nerf_hip_backward_scratch_bytes", "nerf_hip_render_backward",
            "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_legacy_packed_bytes",
-           "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward", "nerf_hip_timing",
+           "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward",
+           "nerf_hip_legacy_train_workspace_bytes", "nerf_hip_legacy_grad_elements",
+           "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_timing",
            "nerf_hip_timing_read")
 
 

@@ -19,19 +19,16 @@
 //      sums of dY).
 //   4. nerf_grad_reduce_kernel — sums the slabs in a fixed order into the flat gradient vector
 //      (state_dict order, PyTorch layouts; undoes the layer-0 column permutation).
-#include <type_traits>
-
-#include "nerf_device.h"
+#include "nerf_backward_common.h"
 
 using namespace nerf_layout;
 using namespace nerf_device;
+using namespace nerf_bwd;
 
 namespace {
 
 constexpr int kGbFloats = 5 * 2 * kHidden;                         // gamma/beta partials per workgroup
 constexpr int kBwdLdsBytes = kRingBytes + kSmallLdsBytes + kGbFloats * 4;   // 74.25 KiB
-constexpr int kMaxSplits = 128;
-constexpr int kMaxDataGrid = 1024;
 
 // partial-slab layout (floats) for one split
 constexpr int kSlabW0 = 0;                                          // [256][96] kernel column order
@@ -58,253 +55,14 @@ struct BwdArgs {
 
 typedef WeightPipe<kBwdStages> BwdPipe;
 
-// gamma/beta gradient partials of a workgroup live in LDS ([layer][gamma|beta][256]).  Each wave
-// row-reduces its 16 samples, then the four waves add their values in wave order, one wave per
-// stage barrier of the MFMA loop that follows (no atomics: bitwise reproducible).
-struct GammaBetaTurn {
-    float* dst;                 // this lane's 4 gamma slots; beta slots at +256
-    f32x4 kg, kb;
-    int wave;
-    __device__ __forceinline__ void operator()(int t) const {
-        if (t < kWavesPerWg && wave == t) {
-            f32x4* pg = (f32x4*)dst;
-            f32x4* pb = (f32x4*)(dst + kHidden);
-            *pg = *pg + kg;
-            *pb = *pb + kb;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // landed before the next barrier
-        }
-    }
-};
-
-// Stage hook of the data-gradient MFMA loops: the wave-ordered gamma/beta adds, and at stage 1
-// the loads of the NEXT LayerNorm backward's saved x_hat tile and 1/std, so that their HBM latency
-// runs under this layer's MFMAs instead of in front of the LayerNorm arithmetic.  (Stage 1, not 0:
-// the loads then sit behind one stage's DMA in the vmcnt queue and the next stage's counted wait
-// retires them only after a whole stage of MFMAs.)
-struct BwdHook {
-    GammaBetaTurn& turn;
-    const float* xhat_row;      // this lane's 4 features of tile 0 in its sample's row
-    const float* rstd_ptr;
-    f32x4 (&xh)[16];
-    float& rstd;
-    __device__ __forceinline__ void operator()(int t) const {
-        turn(t);
-        if (t == 1) {
-#pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * 16);
-            rstd = *rstd_ptr;
-        }
-    }
-};
-
-// LayerNorm + ReLU backward for hidden layer L on the register tile.
-//   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
-//   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
-//   kScaled (split-precision chain): acc holds dL/dx times the per-sample power of two `unscale`
-//   undoes (the B operands were scaled into the f16 range, the weights carry 2^kWScaleLog2)
-template <bool kScaled = false>
-__device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
-                                                    f32x4 (&acc)[16], float (&act)[64],
-                                                    const f32x4 (&xh)[16], float rstd,
-                                                    float* dy_row, float* gb_l, GammaBetaTurn& turn,
-                                                    float unscale = 1.0f) {
-    const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
-    const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
-    float s1 = 0.f, s2 = 0.f;
-    f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        const f32x4 ga = gam[T], be = bet[T];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float z = __builtin_fmaf(xh[T][r], ga[r], be[r]);
-            float dz;               // (if constexpr: a ?: on kScaled costs the fp32 kernel 60 spilled registers)
-            if constexpr (kScaled) dz = z > 0.f ? acc[T][r] * unscale : 0.f;
-            else dz = z > 0.f ? acc[T][r] : 0.f;
-            // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
-            const float rb = row_sum(dz);
-            const float rg = row_sum(dz * xh[T][r]);
-            if (j == T) {
-                keep_b[r] = rb;
-                keep_g[r] = rg;
-            }
-            const float gdz = ga[r] * dz;
-            s1 += gdz;
-            s2 = __builtin_fmaf(gdz, xh[T][r], s2);
-            acc[T][r] = gdz;
-        }
-    }
-    turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
-    turn.kg = keep_g;
-    turn.kb = keep_b;
-    const float m1 = group_sum(s1) * (1.0f / 256.0f);
-    const float m2 = group_sum(s2) * (1.0f / 256.0f);
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
-        f32x4 dy;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dy[r] = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
-            act[4 * T + r] = dy[r];
-        }
-        *(f32x4*)(dy_row + T * 16) = dy;
-    }
-}
-
-// Compositing backward: one wave per padded ray slot, chunks walked last to first (the
-// transmittance gradient is a suffix sum along the ray); writes dL/d(out) of every sample row-major
-// ([sp][64]: the B operand of the data-gradient chain and the dY of layer 5's weight gradient).
+// Compositing backward (nerf_backward_common.h): one wave per padded ray slot.
 __global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs ba) {
-    const NerfHipRenderArgs& a = ba.a;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, g = lane >> 4;
-    const int P = ba.intervals;
-    const int chunks = ba.chunks;
-    float* const ws = a.train_workspace;
-    const int64_t slot = (int64_t)blockIdx.x * kWavesPerWg + wave;
-    if (slot * chunks * 16 >= ba.L.mp) return;
-    int64_t local = slot;
-    const bool ray_ok = local < a.n_rays;
-    if (!ray_ok) local = a.n_rays - 1;
-
-        // upstream gradients of this ray
-        const float g0 = ray_ok ? ba.d_rgb[local * 3 + 0] : 0.f;
-        const float g1 = ray_ok ? ba.d_rgb[local * 3 + 1] : 0.f;
-        const float g2 = ray_ok ? ba.d_rgb[local * 3 + 2] : 0.f;
-        const bool with_seg = ba.d_seg != nullptr;
-
-        float suffix = 0.f;                       // sum_{m in later chunks} q_m w_m
-        for (int c = chunks - 1; c >= 0; --c) {
-            const int s = c * kSamplesPerWave + j;
-            const bool ok = ray_ok && s < P;
-            const int64_t tile = slot * chunks + c;
-            const int64_t sp = tile * 16 + j;
-
-            // ---- compositing backward -> dL/d(out) in accumulator layout ----
-            f32x4 dout[4];
-            {
-                const f32x4 cmp = *(const f32x4*)(ws + ba.L.comp + sp * 4);   // alpha, T, dist, density
-                const float alpha = cmp.x, t_excl = cmp.y, dist = cmp.z, dens = cmp.w;
-                f32x4 out[4];
-                const float* otile = ws + ba.L.out + tile * 1024 + lane * 4;
-#pragma unroll
-                for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
-                const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
-                // colour: logits on lane group 0 (slots 1..3)
-                const float sr = 1.0f / (1.0f + expf(-out[0].y));
-                const float sg = 1.0f / (1.0f + expf(-out[0].z));
-                const float sb = 1.0f / (1.0f + expf(-out[0].w));
-                float q = __shfl((g0 * sr + g1 * sg) + g2 * sb, j);           // dL/dw, colour part
-                // segmentation: v_sc = log(w + 1e-10) + log_softmax(x_s)[c]; seg_c = logsumexp_s v_sc
-                float m = 0.f, logz = 0.f, lw = 0.f, srho = 0.f;
-                float gseg[16], oseg[16];         // dL/dseg and forward seg of this lane's slots
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gseg[i] = oseg[i] = 0.f;
-                if (with_seg) {
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = 16 * T + 4 * g + r;
-                            if (ray_ok && n >= 4 && n < kOut) {
-                                gseg[4 * T + r] = ba.d_seg[local * kSegClasses + (n - 4)];
-                                oseg[4 * T + r] = a.seg[local * kSegClasses + (n - 4)];
-                            }
-                        }
-                    m = -__builtin_inff();
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
-                    m = group_max(m);
-                    float z = 0.f;
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) z += expf(out[T][r] - m);
-                    logz = logf(group_sum(z));
-                    lw = logf(w + 1e-10f);
-#pragma unroll
-                    for (int T = 0; T < 4; ++T)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) {
-                                const float rho = expf(lw + ((out[T][r] - m) - logz) - oseg[4 * T + r]);
-                                srho = __builtin_fmaf(gseg[4 * T + r], rho, srho);
-                            }
-                    srho = ok ? group_sum(srho) : 0.f;
-                    q += srho / (w + 1e-10f);
-                }
-                const float qw = ok ? q * w : 0.f;
-                const float suf_incl = row_suffix_sum(qw);
-                const float suf_excl = suffix + row_shift_down(0.f, suf_incl);
-                suffix += __shfl(suf_incl, lane & 48);
-                const float dalpha = -q * t_excl + suf_excl / (alpha + 1e-10f);
-                const float dsigma = (ok && dens > 0.f) ? dalpha * (-dist * alpha) : 0.f;
-#pragma unroll
-                for (int T = 0; T < 4; ++T)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = 16 * T + 4 * g + r;
-                        float v = 0.f;
-                        if (n >= 4 && n < kOut && with_seg) {
-                            const float lp = (out[T][r] - m) - logz;
-                            const float rho = expf(lw + lp - oseg[4 * T + r]);
-                            v = gseg[4 * T + r] * rho - expf(lp) * srho;
-                        }
-                        dout[T][r] = v;
-                    }
-                if (g == 0) {
-                    dout[0].x = dsigma;
-                    dout[0].y = g0 * w * sr * (1.0f - sr);
-                    dout[0].z = g1 * w * sg * (1.0f - sg);
-                    dout[0].w = g2 * w * sb * (1.0f - sb);
-                }
-                if (!ok) {
-#pragma unroll
-                    for (int T = 0; T < 4; ++T) dout[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
-#pragma unroll
-                for (int T = 0; T < 4; ++T) *(f32x4*)(drow + T * 16) = dout[T];
-            }
-
-        }
+    CompositeBwd cb;
+    cb.d_rgb = ba.d_rgb, cb.d_seg = ba.d_seg;
+    cb.intervals = ba.intervals, cb.chunks = ba.chunks;
+    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5 = ba.L.dy5;
+    composite_bwd_body(ba.a, cb);
 }
-
-// Split-precision data gradient: a sample's dY row becomes f16 pairs after an exact per-sample
-// power-of-two scaling that puts its largest magnitude in [2^12, 2^13) (the chain is linear in dY,
-// so the scale is undone on the accumulators; f16 keeps 11 bits per half down to 2^-14, i.e. an
-// element 2^-16 of the row's largest still has all 22 bits).  Returns the scale; `unscale` also
-// removes the weights' 2^kWScaleLog2.
-__device__ __forceinline__ float row_scale(float amax_lane, float& unscale, float& amax) {
-    amax = group_max(amax_lane);
-    uint32_t e = __builtin_bit_cast(uint32_t, amax) >> 23;            // amax >= 0
-    e = e < 32u ? 32u : e;                                            // rows below 2^-95: treated as 2^-95
-    unscale = __builtin_bit_cast(float, (e - 12u - (uint32_t)kWScaleLog2) << 23);
-    return __builtin_bit_cast(float, (266u - e) << 23);               // 2^(12 - (e - 127))
-}
-__device__ __forceinline__ float abs_max4(float m, const f32x4& v) {
-    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)));
-    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
-}
-
-// Stage hook of the split-precision loops: only the wave-ordered gamma/beta adds (the x_hat
-// prefetch is issued before the loop: a 0.2 us stage cannot hide an HBM load behind one hand-over).
-// The weight-gradient kernel's f16-pair form needs ONE scale per layer for the whole batch: every
-// wave folds its samples' maxima into an LDS word of its workgroup (integer max on the bits of a
-// non-negative float: order-independent, so still bitwise reproducible).
-__device__ __forceinline__ void note_max(int* word, float amax, int lane) {
-    const float w = row_max(amax);                // lanes 0..15 = the wave's 16 samples
-    if (lane == 0) atomicMax(word, __builtin_bit_cast(int, w));
-}
-
-struct TurnHook {
-    GammaBetaTurn& turn;
-    __device__ __forceinline__ void operator()(int t) const { turn(t); }
-};
 
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -495,510 +253,25 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     if (threadIdx.x < 8) ba.dymax[(int64_t)blockIdx.x * 8 + threadIdx.x] = __builtin_bit_cast(float, wmax[threadIdx.x]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// weight gradients: dW[out][in] = sum_s dY[s][out] X[s][in], split over sample tiles
-// ---------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kKs = 32;                          // samples per LDS tile
-
-template <int OUT_W, int IN_W, int TO, int TI>
-struct WgradShape {
-    static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
-    static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
-    static constexpr int kTileBytes = kDyBytes + kXBytes;
-    static constexpr int kPieces = kTileBytes / 1024;          // 1 KiB LDS-DMA pieces per tile
-    static constexpr int kPiecesPerWave = kPieces / 4;
-    static_assert(kPieces % 4 == 0, "pieces must split over 4 waves");
-};
-typedef WgradShape<kHidden, kEncIn, 2, 3> ShapeL0;        // waves: out tiles 2w..2w+1, all 3 in tiles
-typedef WgradShape<kHidden, kHidden, 4, 4> ShapeHid;       // waves 2x2: 4x4 tiles each
-typedef WgradShape<kOutPad, kHidden, 2, 2> ShapeL5;        // waves: both out tiles, in tiles 2w..2w+1
-
-// ---------------------------------------------------------------------------------------------
-// The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
-// bits, by truncation, and bf16 has fp32's exponent range, so gradients of any magnitude are
-// represented exactly — an f16 pair would need a data-dependent scale for dY) and six
-// v_mfma_f32_32x32x16_bf16 per product: hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi, fp32
-// accumulate; the dropped terms are <= 2^-24 relative.  16 samples per MFMA instead of 2:
-// 96 x 32 cycles per 16 samples against 128 x 64.
-//   A operand: lane l holds dY[sample 8 (l >> 5) + jj][out row l & 31], jj = 0..7
-//   B operand: lane l holds  X[sample 8 (l >> 5) + jj][in  col l & 31]
-//   C/D: as v_mfma_f32_32x32x2_f32 (the epilogue and the reduce kernel do not change)
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct Bf3 {
-    bf8 h, m, l;
-};
-
-// eight fp32 values -> their (hi, mid, lo) bf16 truncations, element jj = value jj
-__device__ __forceinline__ Bf3 split_bf3(const float (&x)[8]) {
-    u32x4 ph, pm, pl;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        unsigned hb[2], mb[2], lb[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float v = x[2 * p + e];
-            hb[e] = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
-            const float r1 = v - __builtin_bit_cast(float, hb[e]);          // exact
-            mb[e] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-            const float r2 = r1 - __builtin_bit_cast(float, mb[e]);         // exact
-            lb[e] = __builtin_bit_cast(unsigned, r2);
-        }
-        // upper halves of (value 2p, value 2p + 1) -> one dword, value 2p in the low half
-        ph[p] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
-        pm[p] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
-        pl[p] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
-    }
-    Bf3 r;
-    r.h = __builtin_bit_cast(bf8, ph);
-    r.m = __builtin_bit_cast(bf8, pm);
-    r.l = __builtin_bit_cast(bf8, pl);
-    return r;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf(const bf8& a, const bf8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The bf16-triple GEMM as ONE continuous stream of 16-sample k-steps over a 4-slot LDS ring
-// (round 2; round 1's form — 32-sample tiles in two buffers — is in the history: commit 39d705c).
-// Why: with one wave per SIMD nothing hides a tile hand-over.  The two-buffer form exposed, per
-// 32-sample tile, the conversion of the tile's first operands (5 operands x 8 values x ~7 VALU)
-// and a vmcnt(0) that waited for a tile whose DMA had been issued only half a tile earlier; the
-// matrix pipe was ~50 % busy.  Here
-//   * a ring slot holds ONE k-step (16 samples: [16][OutW] dY then [16][InW] X);
-//   * during step t the VALU converts A(t, a + 1) from slot t and, for step t + 1, A(t + 1, 0) and
-//     all B operands from slot t + 1, so no conversion is ever exposed after the prologue;
-//   * the DMA of step t + 3 is issued during step t into the slot step t - 1 just vacated, i.e. it
-//     has two whole steps to land; the hand-over at the end of step t waits only for this wave's
-//     pieces of step t + 2 (counted vmcnt: the pieces of step t + 3 stay in flight), then one
-//     barrier makes every wave's pieces visible and proves every wave has left step t
-//     (write-after-read safety of the slot that step t + 4's DMA takes next).
-// The DMA is issued from inline asm (as in WeightPipe::issue): with the builtin the compiler's
-// wait-count pass would put a vmcnt(0) in front of every LDS read.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRingStep = 16;                    // samples per ring slot = one MFMA k-step
-constexpr int kRingSlots = 4;
-constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 KiB (hidden shape)
-static_assert(kRingSlots * kRingSlotBytes == 2 * ShapeHid::kTileBytes, "same LDS as the two-buffer form");
-
-// N (<= 4) consecutive 1 KiB pieces: global (uniform base + lane * 16 + k KiB) -> LDS (base + k KiB)
-template <int N>
-__device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
-    static_assert(N >= 1 && N <= 4, "immediate offsets reach 3 KiB");
-    const uint64_t base_u = (uint64_t)(uintptr_t)src;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
-    const uint64_t sbase = ((uint64_t)hi << 32) | lo;
-    const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
-    uint32_t m0_saved;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 2\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        ".if %c4 > 1\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t.endif\n\t"
-        ".if %c4 > 2\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\t.endif\n\t"
-        ".if %c4 > 3\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t.endif\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(m0_saved)
-        : "v"(lane * 16), "s"(d), "s"(sbase), "n"(N)
-        : "memory");
-}
-
-// DMA instructions every wave issues per k-step (the same count on every wave: the hand-over's
-// vmcnt is an immediate).  dY rows are kOutW floats, X rows kInW: both regions are contiguous.
-template <class Sh>
-struct RingPlan {
-    static constexpr int kDyPieces = kRingStep * Sh::kOutW * 4 / 1024;    // 16 / 16 / 4
-    static constexpr int kXPieces = kRingStep * Sh::kInW * 4 / 1024;      // 6 / 16 / 16
-    static constexpr int kDyPerWave = (kDyPieces + 3) / 4, kXPerWave = (kXPieces + 3) / 4;
-    static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
-    static constexpr int kXOffset = kRingStep * Sh::kOutW * 4;            // X behind dY in the slot
-};
-
-// part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
-// past the region re-fetches the region's last pieces instead (same bytes to the same place).
-template <class Sh, int kPart>
-__device__ __forceinline__ void ring_issue_part(const float* dy, const float* x, int64_t sample0, char* slot,
-                                                int wave, int lane) {
-    typedef RingPlan<Sh> P;
-    constexpr int total = kPart == 0 ? P::kDyPieces : P::kXPieces;
-    constexpr int per = kPart == 0 ? P::kDyPerWave : P::kXPerWave;
-    int first = wave * per;
-    if (first + per > total) first = total - per;
-    const char* src = kPart == 0 ? (const char*)(dy + sample0 * Sh::kOutW) : (const char*)(x + sample0 * Sh::kInW);
-    char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
-    ring_dma<per>(src + first * 1024, dst + first * 1024, lane);
-}
-
-struct H2 {                   // an operand as f16 pairs: value = (h + l) / scale
-    h8 h, l;
-};
-__device__ __forceinline__ f32x16 mfma_hw(const h8& a, const h8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// kF16 (the split-precision training mode): operands as f16 PAIRS instead of bf16 triples — three
-// v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, and 4 instead of ~7 VALU per value.
-// X = relu(gamma x_hat + beta) (or the encoded inputs) is O(1) and enters times 2^4 as in the
-// forward; dY enters times ONE power of two per layer and launch, chosen from the largest |dY| of
-// the whole batch (`dymax`, written by the data-gradient kernel) so that it lands in [2^12, 2^13):
-// a sample's row cannot have its own scale here because the product sums over samples.  Elements
-// more than 2^16 below the batch maximum lose relative precision, but never more than 2^-38 of that
-// maximum absolutely — below fp32 rounding of any sum the large elements take part in.  (The bf16
-// form needs no scale: bf16 has fp32's exponent range; it stays the fp32 training mode's arithmetic.)
-template <class Sh, bool kAffine, bool kF16 = false>
-__device__ __forceinline__ void wgrad_body_ring(const BwdArgs& ba, char* smem, const float* dy, const float* x,
-                                                const float* small_prev, int w_off, int b_off, int split,
-                                                int max_index = 0) {
-    typedef RingPlan<Sh> P;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    int out0, in0;                                // first 32-wide tile of this wave
-    if (Sh::kTo == 4) { out0 = 4 * (wave >> 1); in0 = 4 * (wave & 1); }
-    else if (Sh::kTi == 3) { out0 = 2 * wave; in0 = 0; }
-    else { out0 = 0; in0 = 2 * wave; }
-
-    float ga[Sh::kTi], be[Sh::kTi];
-#pragma unroll
-    for (int b = 0; b < Sh::kTi; ++b) {
-        const int f = 32 * (in0 + b) + (lane & 31);
-        const int idx = (((f & 15) >> 2) * 16 + (f >> 4)) * 4 + (f & 3);
-        ga[b] = kAffine ? small_prev[kHidden + idx] : 1.0f;
-        be[b] = kAffine ? small_prev[2 * kHidden + idx] : 0.f;
-        if (kF16) {                               // X enters the MFMAs times 2^kXScaleLog2
-            ga[b] *= (float)(1 << kXScaleLog2);
-            be[b] *= (float)(1 << kXScaleLog2);
-        }
-    }
-    float a_scale = 1.0f, un_scale = 1.0f;        // dY scale and what divides it (and X's) out again
-    if (kF16) {
-        float m = 0.f;
-        for (int q = threadIdx.x; q < ba.data_grid; q += 256) m = __builtin_fmaxf(m, ba.dymax[(int64_t)q * 8 + max_index]);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
-        float* red = (float*)smem;
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        m = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
-        __syncthreads();                          // the ring's DMA may overwrite `red` from here on
-        uint32_t e = __builtin_bit_cast(uint32_t, m) >> 23;
-        e = e < 32u ? 32u : e;
-        a_scale = __builtin_bit_cast(float, (266u - e) << 23);                      // 2^(12 - (e - 127))
-        un_scale = __builtin_bit_cast(float, (e - 12u - (uint32_t)kXScaleLog2) << 23);
-    }
-
-    f32x16 acc[Sh::kTo][Sh::kTi];
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[Sh::kTo];
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a) bsum[a] = 0.f;
-
-    const int64_t tile_begin = (int64_t)split * ba.tiles_per_split;
-    int64_t tile_end = tile_begin + ba.tiles_per_split;
-    if (tile_end > ba.n_tiles) tile_end = ba.n_tiles;
-    const int64_t n_steps = tile_end > tile_begin ? 2 * (tile_end - tile_begin) : 0;   // even
-    const int64_t sample_begin = tile_begin * kKs;
-    const int i = lane & 31, kk = lane >> 5;
-
-    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * kRingSlotBytes; };
-    auto issue_step = [&](int64_t t) {            // all pieces of step t (prologue)
-        ring_issue_part<Sh, 0>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
-        ring_issue_part<Sh, 1>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
-    };
-    auto b_value = [&](float raw, int b) {
-        return kAffine ? __builtin_fmaxf(__builtin_fmaf(raw, ga[b], be[b]), 0.f) : (kF16 ? raw * ga[b] : raw);
-    };
-
-    constexpr int kBPerSlot = (Sh::kTi + Sh::kTo - 1) / Sh::kTo;
-    constexpr int kPerProduct = kF16 ? 3 : 6;
-    constexpr int kMfmas = kPerProduct * Sh::kTi;             // per slot
-    constexpr int kLead = kMfmas / 6;
-    // conversion work items per operand — bf16: 8 values + 2 packing items; f16: 4 value pairs
-    // (scale / affine) + 4 pair splits (hi = pkrtz, two residuals, lo = pkrtz)
-    constexpr int kItemsPerOp = kF16 ? 8 : 10;
-    constexpr int kItems = kItemsPerOp * (1 + kBPerSlot);
-    typedef typename std::conditional<kF16, H2, Bf3>::type Operand;
-    static_assert(Sh::kTo % 2 == 0, "the A operand sets ping-pong slot by slot");
-
-    // One k-step: MFMAs on (at[0] of slot 0, bcur) while the VALU builds the next A operands and bnext.
-    // at[2]: A operand sets, slot a uses at[a & 1] and converts into at[(a & 1) ^ 1].
-    Operand at[2];
-    // last_tag: the job's last step converts nothing for a step behind it (its own code instance, so the
-    // steady-state steps carry no selects: a v_cndmask costs 18 cycles here, a plain VALU op 5)
-    auto k_step = [&](auto last_tag, int64_t t, Operand (&bcur)[Sh::kTi], Operand (&bnext)[Sh::kTi]) {
-        constexpr bool kLast = decltype(last_tag)::value;
-        constexpr bool has_next = !kLast;
-        // one lane base per source; everything else in an address is a compile-time constant, so the
-        // reads take immediate offsets (and pair up as ds_read2st64_b32) instead of one v_add each
-        const float* dyt = (const float*)slot_of(t) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
-        const float* dyn = (const float*)slot_of(t + 1) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
-        const float* xn = (const float*)(slot_of(t + 1) + P::kXOffset) + (8 * kk) * Sh::kInW + 32 * in0 + i;
-        const bool issue_more = t + 3 < n_steps;
-        char* fill = slot_of(t + 3);
-#pragma unroll
-        for (int a = 0; a < Sh::kTo; ++a) {
-            // the DMA of step t + 3: dY pieces behind the first slot's first MFMA, X pieces behind the second's
-            const int na = a + 1 < Sh::kTo ? a + 1 : 0;
-            const float* asrc = a + 1 < Sh::kTo ? dyt : dyn;
-            float raw[1 + kBPerSlot][8];
-            const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
-            if (next_a) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc[jj * Sh::kOutW + 32 * na];
-            }
-#pragma unroll
-            for (int q = 0; q < kBPerSlot; ++q) {
-                const int b = a * kBPerSlot + q;
-                if (b < Sh::kTi && has_next) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[jj * Sh::kInW + 32 * b];
-                }
-            }
-            unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
-            u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
-            h2 qh[1 + kBPerSlot][4], ql[1 + kBPerSlot][4];   // f16 form: pair p of the operand, hi / lo
-            const Operand& ac = at[a & 1];
-            Operand& an = at[(a & 1) ^ 1];
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kF16) {
-                // f16 form: the slot's 3 kTi MFMAs and its conversions (4 dependent levels per value
-                // pair: scale, pkrtz, residual, pkrtz) handed to the scheduler as ONE region with the
-                // pattern "1 MFMA, then 6 VALU" — pinned value by value (as the bf16 form below does) each
-                // MFMA gap holds one dependent chain, which runs at 1.7x its issue time
-#pragma unroll
-                for (int m = 0; m < kMfmas; ++m) {
-                    const int b = m / kPerProduct, tt = m % kPerProduct;
-                    acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
-                }
-                if (a < 2 && issue_more) {
-                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                }
-#pragma unroll
-                for (int op = 0; op < 1 + kBPerSlot; ++op) {
-                    const int bq = a * kBPerSlot + (op - 1);
-                    if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
-                    if (op == 0 && !next_a) continue;
-                    float v[8];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        if (op > 0) v[w] = b_value(raw[op][w], bq);
-                        else {
-                            bsum[na] += raw[op][w];       // unscaled: the scaled value then dies in its split
-                            asm("" : "+v"(bsum[na]));     // (keeps SLP from pairing the adds into v_pk_add_f32
-                                                          //  with an op_sel swap: isa_hazards.py rule R5)
-                            v[w] = raw[op][w] * a_scale;
-                        }
-                    }
-                    Operand r;
-                    split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, r.h, r.l);
-                    if (op == 0) an = r;
-                    else bnext[bq] = r;
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8 * (1 + kBPerSlot), 0);     // the raw LDS reads (at most)
-#pragma unroll
-                for (int m = 1; m < kMfmas; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
-            }
-#pragma unroll
-            for (int m = 0; m < kMfmas; ++m) {
-                const int b = m / kPerProduct, tt = m % kPerProduct;
-                if constexpr (kF16) {
-                    acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
-                } else {
-                    const bf8& ta = tt == 5 ? ac.l : (tt == 2 || tt == 3 ? ac.m : ac.h);
-                    const bf8& tb = tt == 4 ? bcur[b].l : (tt == 1 || tt == 3 ? bcur[b].m : bcur[b].h);
-                    acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (m == 0 && a < 2 && issue_more) {
-                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                }
-#pragma unroll
-                for (int it = 0; it < kItems; ++it) {
-                    if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
-                    const int op = it / kItemsPerOp, w = it % kItemsPerOp;   // op 0: next A operand, 1..: B operands of step t + 1
-                    const int bq = a * kBPerSlot + (op - 1);
-                    if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
-                    if (op == 0 && !next_a) continue;
-                    if constexpr (kF16) {
-                        if (w < 4) {                  // values 2w, 2w + 1: scale (dY) or affine + ReLU (X)
-#pragma unroll
-                            for (int e2 = 0; e2 < 2; ++e2) {
-                                float val = raw[op][2 * w + e2];
-                                asm volatile("" : "+v"(val));
-                                if (op > 0) val = b_value(val, bq);
-                                else {
-                                    bsum[na] += val;
-                                    val *= a_scale;
-                                }
-                                asm volatile("" : "+v"(val));
-                                raw[op][2 * w + e2] = val;
-                            }
-                        } else {                      // pair w - 4: hi = pkrtz, residuals, lo = pkrtz
-                            const int pp = w - 4;
-                            const float v0 = raw[op][2 * pp], v1 = raw[op][2 * pp + 1];
-                            qh[op][pp] = pack_rtz(v0, v1);
-                            ql[op][pp] = pack_rtz(residual<0>(v0, qh[op][pp]), residual<1>(v1, qh[op][pp]));
-                            asm volatile("" : "+v"(ql[op][pp]));
-                            if (pp == 3) {
-                                Operand r;
-                                r.h = join8(qh[op][0], qh[op][1], qh[op][2], qh[op][3]);
-                                r.l = join8(ql[op][0], ql[op][1], ql[op][2], ql[op][3]);
-                                if (op == 0) an = r;
-                                else bnext[bq] = r;
-                            }
-                        }
-                    } else {
-                    if (w < 8) {
-                        float val = raw[op][w];
-                        asm volatile("" : "+v"(val));
-                        if (op > 0) val = b_value(val, bq);
-                        // bias gradient: every dY value of the wave's out tiles is converted exactly once
-                        if (op == 0) bsum[na] += val;
-                        th[op][w] = __builtin_bit_cast(unsigned, val) & 0xffff0000u;
-                        const float r1 = val - __builtin_bit_cast(float, th[op][w]);
-                        tm[op][w] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-                        tl[op][w] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, tm[op][w]));
-                        asm volatile("" : "+v"(tl[op][w]));
-                    } else {
-#pragma unroll
-                        for (int pp = 2 * (w - 8); pp < 2 * (w - 8) + 2; ++pp) {
-                            unsigned lo_h = th[op][2 * pp], lo_m = tm[op][2 * pp], lo_l = tl[op][2 * pp];
-                            asm volatile("" : "+v"(lo_h), "+v"(lo_m), "+v"(lo_l));
-                            ph[op][pp] = __builtin_amdgcn_perm(th[op][2 * pp + 1], lo_h, 0x07060302u);
-                            pm[op][pp] = __builtin_amdgcn_perm(tm[op][2 * pp + 1], lo_m, 0x07060302u);
-                            pl[op][pp] = __builtin_amdgcn_perm(tl[op][2 * pp + 1], lo_l, 0x07060302u);
-                            asm volatile("" : "+v"(ph[op][pp]), "+v"(pm[op][pp]), "+v"(pl[op][pp]));
-                        }
-                        if (w == 9) {
-                            Bf3 r;
-                            r.h = __builtin_bit_cast(bf8, ph[op]);
-                            r.m = __builtin_bit_cast(bf8, pm[op]);
-                            r.l = __builtin_bit_cast(bf8, pl[op]);
-                            if (op == 0) an = r;
-                            else bnext[bq] = r;
-                        }
-                    }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // hand-over: this wave's pieces of step t + 2 have landed (the kPerWave pieces of step t + 3,
-        // issued above, may still fly), its LDS reads are done; behind the barrier every wave's are
-        if (issue_more) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(P::kPerWave) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    if (n_steps > 0) {
-        // prologue: three steps in flight, the first two landed; step 0's operands converted up front
-        issue_step(0);
-        issue_step(1);
-        if (n_steps > 2) {
-            issue_step(2);
-            asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(P::kPerWave) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        Operand b0[Sh::kTi], b1[Sh::kTi];
-        auto convert = [&](const float (&v)[8]) {
-            if constexpr (kF16) {
-                Operand r;
-                split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, r.h, r.l);
-                return r;
-            } else {
-                return split_bf3(v);
-            }
-        };
-        {
-            const float* dyt = (const float*)slot_of(0);
-            const float* xt = (const float*)(slot_of(0) + P::kXOffset);
-#pragma unroll
-            for (int b = 0; b < Sh::kTi; ++b) {
-                float v[8];
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = b_value(xt[(8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i], b);
-                b0[b] = convert(v);
-            }
-            float v[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                v[jj] = dyt[(8 * kk + jj) * Sh::kOutW + 32 * out0 + i];
-                bsum[0] += v[jj];
-                v[jj] *= a_scale;
-            }
-            at[0] = convert(v);
-        }
-        const std::false_type more_steps;
-        const std::true_type last_step;
-        for (int64_t t = 0; t + 2 < n_steps; t += 2) {    // two steps per trip: the B sets swap roles
-            k_step(more_steps, t, b0, b1);
-            k_step(more_steps, t + 1, b1, b0);
-        }
-        k_step(more_steps, n_steps - 2, b0, b1);
-        k_step(last_step, n_steps - 1, b1, b0);
-    }
-
-    float* slab = ba.slabs + (int64_t)split * kSlabFloats;
-    const int col = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a)
-#pragma unroll
-        for (int b = 0; b < Sh::kTi; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r] * un_scale;
-            }
-#pragma unroll
-    for (int a = 0; a < Sh::kTo; ++a) {
-        const float both = bsum[a] + __shfl_xor(bsum[a], 32);       // the two 8-sample halves of a k-step
-        if (in0 == 0 && half == 0) slab[b_off + 32 * (out0 + a) + col] = both;
-    }
-}
-
-
 // All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
 // layer-0 / layer-5 jobs fill the tail instead of running half-empty launches of their own.
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
+                      ba.data_grid};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;       // [layer][bias | gamma | beta][256]
     if (job < 4) {                                // layers 1..4: input = LayerNorm+ReLU of layer job
-        wgrad_body_ring<ShapeHid, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+        wgrad_body_ring<ShapeHid, kInputAffineRelu>(jb, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
                                    ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
                                    small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
-                                   kSlabB + (job + 1) * kHidden, split);
+                                   kSlabB + (job + 1) * kHidden);
     } else if (job == 4) {                        // layer 0: input = encoded features
-        wgrad_body_ring<ShapeL0, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, split);
+        wgrad_body_ring<ShapeL0, kInputRaw>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
     } else {                                      // layer 5: input = LayerNorm+ReLU of layer 4
-        wgrad_body_ring<ShapeL5, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
-                                  kSlabW5, kSlabB + 5 * kHidden, split);
+        wgrad_body_ring<ShapeL5, kInputAffineRelu>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                  kSlabW5, kSlabB + 5 * kHidden);
     }
 }
 
@@ -1006,21 +279,22 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
+                      ba.data_grid};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;
     if (job < 4) {
-        wgrad_body_ring<ShapeHid, true, true>(ba, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
+        wgrad_body_ring<ShapeHid, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * kHidden,
                                               ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * kHidden,
                                               small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
-                                              kSlabB + (job + 1) * kHidden, split, job + 1);
+                                              kSlabB + (job + 1) * kHidden, job + 1);
     } else if (job == 4) {
         // layer 0 (the smallest job) stays on bf16 triples: recording the batch maximum of dy[0] in the
         // data-gradient kernel costs that kernel 250-700 B of spills per lane, whichever way it is written
-        wgrad_body_ring<ShapeL0, false, false>(ba, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB,
-                                               split);
+        wgrad_body_ring<ShapeL0, kInputRaw, false>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
     } else {
-        wgrad_body_ring<ShapeL5, true, true>(ba, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
-                                             kSlabW5, kSlabB + 5 * kHidden, split, 5);
+        wgrad_body_ring<ShapeL5, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                             kSlabW5, kSlabB + 5 * kHidden, 5);
     }
 }
 
@@ -1033,29 +307,6 @@ __device__ __forceinline__ int layer0_kernel_column(int feature) {
     const int scale = rem / 3, coord = rem % 3;
     const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
     return 16 * (q / 4) + 4 * g + (q % 4);
-}
-
-// sum of p[0], p[stride], ... (n terms) in a fixed association: sixteen interleaved partial sums,
-// combined pairwise — sixteen independent loads in flight per round trip (the loop is latency-bound:
-// with four, a 128-slab reduction was 32 dependent trips to HBM, 74 us for 156 MB)
-__device__ __forceinline__ float strided_sum(const float* p, int n, int64_t stride) {
-    float acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    int i = 0;
-    for (; i + 16 <= n; i += 16) {
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = p[(int64_t)(i + q) * stride];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += v[q];
-    }
-    for (; i < n; ++i) acc[0] += p[(int64_t)i * stride];
-#pragma unroll
-    for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-        for (int q = 0; q < w; ++q) acc[q] += acc[q + w];
-    return acc[0];
 }
 
 constexpr int kReduceThreads = 256;

@@ -728,5 +728,36 @@ __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t lo
     }
 }
 
+// Compositing of a training forward as a kernel body of its own (one wave per ray over the saved network
+// outputs: `out_off` = padded outputs in tile format [tile][T][lane][r], `comp_off` = [sp][4] whose
+// slot 2 the MLP kernel filled with the distance to the next sample): writes rgb / seg / out_weights
+// and the compositing state (alpha, T_exclusive, dist, density + noise) the backward reads.
+// P = samples per ray that are composited (S - 1 intervals, or S points for the legacy network).
+__device__ __forceinline__ void composite_fwd_body(const NerfHipRenderArgs& a, int P, int chunks, int64_t out_off,
+                                                   int64_t comp_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15;
+    const int64_t local = (int64_t)blockIdx.x * kWavesPerWg + wave;
+    if (local >= a.n_rays) return;
+    float* const ws = a.train_workspace;
+    RayAccum racc;
+    racc.reset();
+    for (int c = 0; c < chunks; ++c) {
+        const int s = c * kSamplesPerWave + j;
+        const bool ok = s < P;
+        const int64_t tile = local * chunks + c;
+        const int64_t sp = tile * 16 + j;
+        f32x4 out[4];
+        const float* otile = ws + out_off + tile * 1024 + lane * 4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
+        float* comp = ws + comp_off + sp * 4;
+        const float dist = comp[2];
+        const float w = composite_chunk<true>(a, P, local, s, ok, lane, out, dist, racc, comp);
+        if (a.out_weights != nullptr && ok && lane < 16) a.out_weights[local * P + s] = w;
+    }
+    store_ray(a, local, true, lane, racc);
+}
+
 }  // namespace nerf_device
 #endif

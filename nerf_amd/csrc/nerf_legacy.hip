@@ -19,60 +19,22 @@
 #include <stdint.h>
 
 #include "nerf_device.h"
+#include "nerf_legacy_layout.h"
 
 using namespace nerf_layout;
 using namespace nerf_device;
+using namespace nerf_legacy;
 
 namespace {
 
-constexpr int kPosFreqs = 10, kDirFreqs = 6;
-constexpr int kPosFeatures = 3 * 2 * kPosFreqs;          // 60: 15 per lane group, padded to 16
-constexpr int kDirFeatures = 3 * 2 * kDirFreqs;          // 36:  9 per lane group, padded to 12
-constexpr int kPosPerGroup = 15, kDirPerGroup = 9;
-constexpr int kPosTiles = 4, kDirTiles = 3;
-constexpr int kWide = 10;                                // LayerNorm layers: block_0 x4, block_1 x4, block_2 x2
-// stages per wide layer (k-groups of 16 input features; the concatenated encodings add 4 / 3)
-__host__ __device__ constexpr int wide_stages(int L) {
-    return L == 0 ? kPosTiles : (L == 4 ? 16 + kPosTiles : (L == 8 ? 16 + kDirTiles : 16));
-}
-// consumption order: L0..L7, density head, L8, L9, color head
-constexpr int kLegacyStages = 4 + 3 * 16 + 20 + 3 * 16 + 1 + 19 + 16 + 1;      // 157
-constexpr int kLegacyBlobFloats = kLegacyStages * kStageFloats;
-constexpr int kLegacySmallPerLayer = 3 * kHidden;                              // bias, gamma, beta
-constexpr int kHeadBiasFloats = 32;                                            // density [16], color [16]
-constexpr int kLegacySmallFloats = kWide * kLegacySmallPerLayer + kHeadBiasFloats;   // 7,712
-// Split-precision ("f16x3") image of the same network (nerf_layout.h: slab format of the main kernel's
-// f16-pair image; weights x 2^8, activations enter x 2^4): wide layer L has KB = inputs / 32 k blocks
-// (2 for layer 0, 8, or 10 with a concatenated encoding padded to two blocks) = 2 KB stages of 8 (out
-// tile, k block) pairs; a head is one stage = the 8 k blocks of its single out tile.
-__host__ __device__ constexpr int wide_blocks(int L) { return L == 0 ? 2 : ((L == 4 || L == 8) ? 10 : 8); }
-constexpr int kLegacyHStages = 4 + 3 * 16 + 20 + 3 * 16 + 1 + 20 + 16 + 1;     // 158
-constexpr int kLegacyHBlobFloats = kLegacyHStages * kStageFloats;
-constexpr int kLegacyHOffset = kLegacyBlobFloats + kLegacySmallFloats;
-constexpr int kLegacyHSmallOffset = kLegacyHOffset + kLegacyHBlobFloats;
-constexpr int kLegacyPackedFloats = kLegacyHSmallOffset + kLegacySmallFloats;
-__host__ __device__ inline int h_stage_of_layer(int L) {    // first stage of wide layer L in the f16 image
-    int s = 0;
-    for (int i = 0; i < L; ++i) s += 2 * wide_blocks(i);
-    return s + (L >= 8 ? 1 : 0);
-}
-constexpr int kHDensityStage = 4 + 3 * 16 + 20 + 3 * 16;     // 120
-constexpr int kHColorStage = kLegacyHStages - 1;
 constexpr int kLegacySmallBytes = (kLegacySmallFloats * 4 + 127) / 128 * 128;
 constexpr int kLegacyLdsBytes = kRingBytes + kLegacySmallBytes;                // 79,104 B -> 2 workgroups / CU
-
-__host__ __device__ inline int stage_of_layer(int L) {      // first stage of wide layer L
-    int s = 0;
-    for (int i = 0; i < L; ++i) s += wide_stages(i);
-    return s + (L >= 8 ? 1 : 0);                             // the density head sits before layer 8
-}
-constexpr int kDensityStage = 4 + 3 * 16 + 20 + 3 * 16;      // 120
-constexpr int kColorStage = kLegacyStages - 1;
 
 struct LegacyKernelArgs {
     NerfHipLegacyArgs l;
     int32_t chunks;             // ceil(S / 16)
-    int64_t groups;             // ceil(n_rays / 4)
+    int64_t groups;             // inference: ceil(n_rays / 4) rays; training: (padded ray, chunk) items / 4
+    LegacyTrainLayout save;     // offsets into render.train_workspace (training forward only)
 };
 
 typedef WeightPipe<kLegacyStages> LegacyPipe;
@@ -106,10 +68,40 @@ __device__ __forceinline__ float encoding_feature(int f, const float (&x)[3], fl
     return sincos_reduced(v * (multiplier * (float)(1 << k)), cosine);
 }
 
+// This lane group's slots of the two encodings (15 of 60 position features in 16 slots, 9 of 36 direction
+// features in 12): PE(position / normalize_position) at the sample t0 along the ray, PE(d / |d|).
+__device__ __forceinline__ void encode_position(const Ray& ray, float t0, const NerfHipLegacyArgs& la, int g,
+                                                float (&pos_act)[64]) {
+#pragma clang fp contract(off)
+    const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
+                        (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
+                        (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
+#pragma unroll
+    for (int q = 0; q < 4 * kPosTiles; ++q)
+        pos_act[q] = q < kPosPerGroup ? encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
+}
+__device__ __forceinline__ void encode_direction(const Ray& ray, float dlen, const NerfHipLegacyArgs& la, int g,
+                                                 float (&dir_act)[64]) {
+    float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
+    if (la.normalize_directions) {
+        const float inv = 1.0f / dlen;
+        dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
+    }
+#pragma unroll
+    for (int q = 0; q < 4 * kDirTiles; ++q)
+        dir_act[q] = q < kDirPerGroup ? encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
+}
+
 // LayerNorm(256, eps 1e-5, affine) of relu(acc) -> act (the next layer's B operands).
 // Lane (j, g) holds features 16 T + 4 g + r of sample j in acc[T][r]; exact two-pass variance.
+// kTrain: also saves a_hat = (relu(y) - mean) / std (row order), 1/std and `shift` = the a_hat of a closed
+// gate ((0 - mean) / std, rounded like a_hat), so that the backward reads the ReLU gate as a_hat > shift.
+// The subtraction and the product are monotonic, so a_hat >= shift always; where an OPEN gate (y > 0, y below
+// half an ulp of the mean) rounds onto `shift`, a_hat is moved one ulp up — the gate the backward sees is exact.
+template <bool kTrain>
 __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const float* small_l, int g,
-                                                float (&act)[64]) {
+                                                float (&act)[64], float* xhat_row = nullptr,
+                                                float* rstd_p = nullptr, float* shift_p = nullptr) {
     float sum = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T)
@@ -130,12 +122,23 @@ __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const fl
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
     const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden + g * 64);
+    const float shift = (0.f - mean) * rstd;                  // <= 0 (mean of ReLU outputs)
+    const float above = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, shift) - 1u);   // next float up (shift < 0)
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
         const f32x4 ga = gam[T], be = bet[T];
+        f32x4 xh;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            act[4 * T + r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
+        for (int r = 0; r < 4; ++r) {
+            xh[r] = (act[4 * T + r] - mean) * rstd;
+            if (kTrain) xh[r] = (act[4 * T + r] > 0.f && xh[r] <= shift) ? above : xh[r];
+            act[4 * T + r] = __builtin_fmaf(xh[r], ga[r], be[r]);
+        }
+        if (kTrain) *(f32x4*)(xhat_row + T * 16) = xh;
+    }
+    if (kTrain && g == 0) {
+        *rstd_p = rstd;
+        *shift_p = shift;
     }
 }
 
@@ -164,6 +167,11 @@ __device__ __forceinline__ f32x4 head_layer(LegacyPipe& pipe, f32x4 acc, const f
     return acc;
 }
 
+// kTrain: the training forward.  Compositing (the only coupling between the chunks of a ray) is then a
+// kernel of its own (nerf_legacy_composite_fwd_kernel), so the unit of work is one (padded ray, chunk) item
+// per wave — a 512-ray batch fills all 2,048 waves — and everything the backward needs is saved:
+// the two encodings, a_hat / 1/std / shift of the ten LayerNorms, the head outputs, the sample spacing.
+template <bool kTrain>
 __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKernelArgs ka) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipLegacyArgs& la = ka.l;
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int S = a.num_samples;
+    float* const ws = a.train_workspace;
 
     float* small = (float*)(smem + kRingBytes);
     for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyBlobFloats + i];
@@ -182,28 +191,25 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
     __syncthreads();
 
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
-        int64_t local = grp * kWavesPerWg + wave;
+        const int64_t unit = grp * kWavesPerWg + wave;
+        const int64_t slot = kTrain ? unit / ka.chunks : unit;       // padded ray slot (workspace rows)
+        int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
         const Ray ray = load_ray(a, local);
         // |d| (sample spacing in space) and the encoded view direction: once per ray
         const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
         float dir_act[64];
-        {
-            float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
-            if (la.normalize_directions) {
-                const float inv = 1.0f / dlen;
-                dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
-            }
-#pragma unroll
-            for (int q = 0; q < 4 * kDirTiles; ++q)
-                dir_act[q] = q < kDirPerGroup ? encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
-        }
+        encode_direction(ray, dlen, la, g, dir_act);
         RayAccum racc;
         racc.reset();
-        for (int c = 0; c < ka.chunks; ++c) {
+        const int c_begin = kTrain ? (int)(unit - slot * ka.chunks) : 0;
+        const int c_end = kTrain ? c_begin + 1 : ka.chunks;
+        for (int c = c_begin; c < c_end; ++c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = s < S;
+            const int64_t tile = slot * ka.chunks + c;        // chunk index in the workspace
+            const int64_t sp = tile * 16 + j;                 // padded sample index
             // sample positions: the fencepost routine of the main kernel on a caller-supplied table
             // (linear in [near, far] for this network, Mildenhall et al. 2020), stratified by u, or
             // explicit per-ray positions
@@ -211,42 +217,56 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
             const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
             const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
             float pos_act[64];
-            {
-#pragma clang fp contract(off)
-                const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
-                                    (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
-                                    (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
+            encode_position(ray, t0, la, g, pos_act);
+            // training: lane-relative bases of this sample's saved rows (+ the tensor's offset)
+            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;
+            float* const stat = kTrain ? ws + sp : nullptr;
+            if (kTrain) {
+                if (g == 0) *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{0.f, 0.f, dist, 0.f};   // (not live across the MLP)
+                float* prow = ws + ka.save.pos + sp * kEncPad + 4 * g;
+                float* drow = ws + ka.save.dir + sp * kEncPad + 4 * g;
 #pragma unroll
-                for (int q = 0; q < 4 * kPosTiles; ++q)
-                    pos_act[q] = q < kPosPerGroup ? encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
+                for (int t = 0; t < 4; ++t) {
+                    *(f32x4*)(prow + 16 * t) = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]};
+                    *(f32x4*)(drow + 16 * t) = t < kDirTiles ? f32x4{dir_act[4 * t], dir_act[4 * t + 1], dir_act[4 * t + 2], dir_act[4 * t + 3]}
+                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             f32x4 acc[16];
             float act[64];
             // ---- block_0 ----
             load_bias(small, g, acc);
             layer_wide<kPosTiles>(pipe, acc, pos_act);
-            relu_layer_norm(acc, small, g, act);
+            relu_layer_norm<kTrain>(acc, small, g, act, xrow + ka.save.xhat[0], stat + ka.save.rstd[0], stat + ka.save.shift[0]);
 #pragma unroll 1
             for (int L = 1; L <= 3; ++L) {
                 const float* sl = small + L * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
                 layer_wide<16>(pipe, acc, act);
-                relu_layer_norm(acc, sl, g, act);
+                relu_layer_norm<kTrain>(acc, sl, g, act, xrow + ka.save.xhat[L], stat + ka.save.rstd[L], stat + ka.save.shift[L]);
             }
             // ---- block_1: [hidden | encoded position] -> 256 ----
             {
                 const float* sl = small + 4 * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
                 layer_wide<16>(pipe, acc, act);
-                layer_wide<kPosTiles>(pipe, acc, pos_act);
-                relu_layer_norm(acc, sl, g, act);
+                if (kTrain) {
+                    // recomputed (same operations, same bits) rather than kept live across four layers: the
+                    // training kernel also carries the save addresses, and 16 more live registers spill
+                    float again[64];
+                    encode_position(ray, t0, la, g, again);
+                    layer_wide<kPosTiles>(pipe, acc, again);
+                } else {
+                    layer_wide<kPosTiles>(pipe, acc, pos_act);
+                }
+                relu_layer_norm<kTrain>(acc, sl, g, act, xrow + ka.save.xhat[4], stat + ka.save.rstd[4], stat + ka.save.shift[4]);
             }
 #pragma unroll 1
             for (int L = 5; L <= 7; ++L) {
                 const float* sl = small + L * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
                 layer_wide<16>(pipe, acc, act);
-                relu_layer_norm(acc, sl, g, act);
+                relu_layer_norm<kTrain>(acc, sl, g, act, xrow + ka.save.xhat[L], stat + ka.save.rstd[L], stat + ka.save.shift[L]);
             }
             // ---- density head ----
             const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
@@ -256,18 +276,30 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
                 const float* sl = small + 8 * kLegacySmallPerLayer;
                 load_bias(sl, g, acc);
                 layer_wide<16>(pipe, acc, act);
-                layer_wide<kDirTiles>(pipe, acc, dir_act);
-                relu_layer_norm(acc, sl, g, act);
+                if (kTrain) {
+                    float again[64];
+                    encode_direction(ray, dlen, la, g, again);
+                    layer_wide<kDirTiles>(pipe, acc, again);
+                } else {
+                    layer_wide<kDirTiles>(pipe, acc, dir_act);
+                }
+                relu_layer_norm<kTrain>(acc, sl, g, act, xrow + ka.save.xhat[8], stat + ka.save.rstd[8], stat + ka.save.shift[8]);
                 const float* sl9 = small + 9 * kLegacySmallPerLayer;
                 load_bias(sl9, g, acc);
                 layer_wide<16>(pipe, acc, act);
-                relu_layer_norm(acc, sl9, g, act);
+                relu_layer_norm<kTrain>(acc, sl9, g, act, xrow + ka.save.xhat[9], stat + ka.save.rstd[9], stat + ka.save.shift[9]);
             }
             const f32x4 col = head_layer(pipe, hb[4 + g], act);
             // ---- compositing (nerf/model.py:438-469, :660): out[0] = (density, r, g, b) on lane group 0
             f32x4 out[4];
             out[0] = f32x4{dens.x, col.x, col.y, col.z};
             out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kTrain) {
+                float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) *(f32x4*)(otile + T * 256) = out[T];
+                continue;
+            }
             const float w = composite_chunk<false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
             if (ray_ok && ok && g == 0) {
                 const int64_t smp = local * S + s;
@@ -280,9 +312,14 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
                 }
             }
         }
-        store_ray(a, local, ray_ok, lane, racc);
+        if (!kTrain) store_ray(a, local, ray_ok, lane, racc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Compositing of the training forward: one wave per ray over the saved head outputs.
+__global__ __launch_bounds__(256) void nerf_legacy_composite_fwd_kernel(const LegacyKernelArgs ka) {
+    composite_fwd_body(ka.l.render, ka.l.render.num_samples, ka.chunks, ka.save.out, ka.save.comp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,14 +520,33 @@ struct LegacyPackArgs {
     float* packed;
 };
 
-__host__ __device__ inline int wide_param(int L) { return L < 8 ? 4 * L : 34 + 4 * (L - 8); }
-__host__ __device__ inline int wide_inputs(int L) { return L == 0 ? kPosFeatures : (L == 4 ? kHidden + kPosFeatures : (L == 8 ? kHidden + kDirFeatures : kHidden)); }
 
 __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kLegacyPackedFloats) return;
     float v = 0.f;
-    if (e >= kLegacyHSmallOffset) {
+    if (e >= kLegacyBwdOffset) {
+        // transposed fp32 image of the data gradient (nerf_legacy_layout.h):
+        // [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i], hidden columns only
+        const int eb = e - kLegacyBwdOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int tin = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int i = lane & 15, g = lane >> 4;
+        int tout;
+        const int L = bwd_layer_of_stage(stage, tout);
+        if (L < 0) {
+            // a head: its outputs sit where the compositing backward leaves dL/d(density, r, g, b):
+            // k slots (g 0, r 0) = density, (g 0, r 1..3) = color
+            if (g == 0) {
+                if (stage == kBwdDensityStage && r == 0) v = pa.p[kDensityW][16 * tin + i];
+                if (stage == kBwdColorStage && r >= 1) v = pa.p[kColorW][(r - 1) * kHidden + 16 * tin + i];
+            }
+        } else {
+            v = pa.p[wide_param(L)][(16 * tout + 4 * g + r) * wide_inputs(L) + 16 * tin + i];
+        }
+    } else if (e >= kLegacyHSmallOffset) {
         // small image of the split-precision path: bias * 2^12, gamma * 2^4, beta * 2^4, head biases * 2^12
         const int i = e - kLegacyHSmallOffset;
         const float sb = (float)(1 << (kWScaleLog2 + kXScaleLog2)), sx = (float)(1 << kXScaleLog2);
@@ -626,6 +682,14 @@ int nerf_hip_legacy_pack_weights(const float* const* params, float* packed, void
     return nerf_common::check_hip(hipGetLastError(), "legacy_pack_weights launch");
 }
 
+size_t nerf_hip_legacy_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
+    if (n_rays <= 0 || num_samples < 2) return 0;
+    const int chunks = (num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
+    return (size_t)make_legacy_train_layout(n_rays, chunks).total * sizeof(float);
+}
+
+size_t nerf_hip_legacy_grad_elements(void) { return (size_t)kLegacyGradElements; }
+
 int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: null args");
     const NerfHipRenderArgs& a = args->render;
@@ -641,9 +705,13 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: neither ray arrays nor cameras given");
     if ((a.rays_o == nullptr) != (a.rays_d == nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: rays_o and rays_d must come together");
-    if (a.seg != nullptr || a.train_workspace != nullptr || a.out_mean != nullptr || a.out_cov != nullptr ||
-        a.out_t != nullptr || a.rng_mode != 0)
-        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: seg / training / Gaussian outputs / in-kernel draws do not exist for this network");
+    if (a.seg != nullptr || a.out_mean != nullptr || a.out_cov != nullptr || a.out_t != nullptr || a.rng_mode != 0)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: seg / Gaussian outputs / in-kernel draws do not exist for this network");
+    const bool train = a.train_workspace != nullptr;
+    if (train && a.out_raw != nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: out_raw is not produced by the training forward");
+    if (train && a.precision != NERF_HIP_PRECISION_FP32)
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "legacy_render_forward: the training forward of this network runs in fp32 arithmetic only");
     if (a.t_values == nullptr && a.t_table == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: t_table / t_values is null");
     if (!(args->normalize_position > 0.f))
@@ -652,7 +720,9 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     LegacyKernelArgs ka;
     ka.l = *args;
     ka.chunks = (a.num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
-    ka.groups = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+    ka.save = make_legacy_train_layout(a.n_rays, ka.chunks);
+    // inference: one ray per wave; training: one (padded ray, chunk) item per wave
+    ka.groups = train ? ka.save.mp / 16 / kWavesPerWg : (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
     if (rc) return rc;
@@ -662,16 +732,21 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: unknown precision");
     const bool half = a.precision == NERF_HIP_PRECISION_F16X3;
-    static unsigned done = 0, done_h = 0;
+    static unsigned done = 0, done_h = 0, done_t = 0;
     rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_h_kernel, kLegacyLdsBytes, device, &done_h)
-              : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel, kLegacyLdsBytes, device, &done);
+        : train ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<true>, kLegacyLdsBytes, device, &done_t)
+                : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<false>, kLegacyLdsBytes, device, &done);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
     if (half) hipLaunchKernelGGL(nerf_legacy_fwd_h_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
-    else hipLaunchKernelGGL(nerf_legacy_fwd_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    else if (train) {
+        hipLaunchKernelGGL(nerf_legacy_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+        const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
+        hipLaunchKernelGGL(nerf_legacy_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
+    } else hipLaunchKernelGGL(nerf_legacy_fwd_kernel<false>, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
     rc = nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

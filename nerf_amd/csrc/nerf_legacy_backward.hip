@@ -1,0 +1,394 @@
+// Backward of the LEGACY (generation-A) 8 x 256 network's fused renderer w.r.t. its 44 parameter tensors
+// (gfx950 only): what PyTorch autograd does behind `loss.backward()` in the notebook's training loop
+// (examples/example.ipynb cell 8; train_conditional_nerf.py:130-135) for the network of examples/nerf.pth.
+// PARITY UNPINNED like the forward (no source of this network is in the reference repository): the spec is
+// autograd through oracle/legacy_oracle.py.
+//
+// Same four launches as the main network's backward (nerf_backward.hip), same machinery
+// (nerf_backward_common.h), no float atomics, bitwise reproducible:
+//   1. nerf_legacy_composite_bwd_kernel — per ray, last chunk first: compositing backward
+//      (nerf/model.py:438-469, :660) -> dL/d(density, r, g, b) of every sample.
+//   2. nerf_legacy_bwd_data_kernel — per 16-sample chunk: dX = W^T dY down the chain color head -> L9 -> L8
+//      (+ density head) -> L7 .. L1 with the transposed fp32 image streamed through the LDS ring, the
+//      LayerNorm / ReLU backward of every wide layer in registers from the saved a_hat, 1/std and gate
+//      threshold; writes dY of the ten wide layers (row order); gamma / beta gradients summed per workgroup
+//      in LDS in wave order.  Layer order here is Linear -> ReLU -> LayerNorm, so the gate is applied LAST.
+//   3. nerf_legacy_wgrad_kernel — the 14 weight-gradient products dW = dY^T X in ONE launch (nine 256 x 256
+//      blocks, the three encoding blocks of L0 / L4 / L8, the two heads), bf16-triple operands, fp32
+//      accumulation; X of a hidden block is rebuilt as gamma a_hat + beta while the operands are read.
+//   4. nerf_legacy_grad_reduce_kernel — partial slabs -> the flat 638,468-element gradient (the 44 tensors
+//      in nerf_legacy_layout.h's order, PyTorch layouts; undoes the encodings' column padding).
+#include "nerf_backward_common.h"
+#include "nerf_legacy_layout.h"
+
+using namespace nerf_layout;
+using namespace nerf_device;
+using namespace nerf_bwd;
+using namespace nerf_legacy;
+
+namespace {
+
+constexpr int kLGbFloats = kWide * 2 * kHidden;                    // gamma / beta partials per workgroup
+constexpr int kGammaFloats = kWide * kHidden;                      // the ten gamma vectors, [L][g][T][r]
+constexpr int kLBwdLdsBytes = kRingBytes + (kGammaFloats + kLGbFloats) * 4;      // 78 KiB -> 2 workgroups / CU
+
+// partial-slab layout (floats) of one split
+constexpr int kHiddenJobs = 9;                                      // L1, L2, L3, L4 (hidden part), L5, L6, L7, L8 (hidden part), L9
+constexpr int kLSlabHid = 0;                                        // 9 x [256][256]
+constexpr int kLSlabEnc = kLSlabHid + kHiddenJobs * kHidden * kHidden;   // 3 x [256][64]: L0, L4 | position, L8 | direction
+constexpr int kLSlabHead = kLSlabEnc + 3 * kHidden * kEncPad;       // 2 x [64][256]: rows of (d density, d r, d g, d b, 0 ..) x x'_7 / x'_9
+constexpr int kLSlabB = kLSlabHead + 2 * kOutPad * kHidden;         // 10 x [256] wide biases, 2 x [64] head rows
+constexpr int kLSlabSpare = kLSlabB + kWide * kHidden + 2 * kOutPad;     // [256] bias sums nobody reads (the encoding blocks)
+constexpr int kLSlabFloats = kLSlabSpare + kHidden;
+constexpr int kWgradJobs = kHiddenJobs + 3 + 2;
+
+typedef WgradShape<kHidden, kEncPad, 2, 2, kMapRows> ShapeEnc;     // waves: out tiles 2w..2w+1, both in tiles
+
+struct LBwdArgs {
+    NerfHipRenderArgs a;
+    const float* d_rgb;
+    int32_t samples, chunks;
+    int64_t groups;
+    LegacyTrainLayout L;
+    float* gb_partial;          // [grid][10][2][256]
+    float* slabs;               // [splits][kLSlabFloats]
+    float* grad;
+    int32_t splits, data_grid;
+    int64_t tiles_per_split, n_tiles;
+};
+
+typedef WeightPipe<kLegacyBwdStages> LBwdPipe;
+
+__global__ __launch_bounds__(256) void nerf_legacy_composite_bwd_kernel(const LBwdArgs ba) {
+    CompositeBwd cb;
+    cb.d_rgb = ba.d_rgb, cb.d_seg = nullptr;
+    cb.intervals = ba.samples, cb.chunks = ba.chunks;
+    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5 = ba.L.dy5;
+    composite_bwd_body(ba.a, cb);
+}
+
+// Stage hook of the data-gradient loops: the wave-ordered gamma / beta adds, and at stage 1 the loads of the
+// NEXT LayerNorm backward's saved a_hat tile, 1/std and gate threshold (nerf_backward_common.h: BwdHook).
+struct LegacyHook {
+    GammaBetaTurn& turn;
+    const float* xhat_row;
+    const float* rstd_ptr;
+    const float* shift_ptr;
+    f32x4 (&xh)[16];
+    float& rstd;
+    float& shift;
+    __device__ __forceinline__ void operator()(int t) const {
+        turn(t);
+        if (t == 1) {
+#pragma unroll
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * 16);
+            rstd = *rstd_ptr;
+            shift = *shift_ptr;
+        }
+    }
+};
+
+// LayerNorm + ReLU backward of one wide layer on the register tile, for the order Linear -> ReLU -> LayerNorm:
+//   in : acc = dL/dx' (the LayerNorm's output = the next Linear's input), saved a_hat tile, 1/std, shift
+//   out: act = dL/dy (the Linear's output) = the next B operands; also stored row-major
+//   d a = (gamma d x' - mean(gamma d x') - a_hat mean(gamma d x' a_hat)) / std ;  d y = d a where y > 0
+__device__ __forceinline__ void relu_layer_norm_bwd(const float* gamma_l, int g, int j, f32x4 (&acc)[16],
+                                                    float (&act)[64], const f32x4 (&xh)[16], float rstd,
+                                                    float shift, float* dy_row, float* gb_l, GammaBetaTurn& turn) {
+    const f32x4* gam = (const f32x4*)(gamma_l + g * 64);
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        const f32x4 ga = gam[T];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dz = acc[T][r];
+            // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
+            const float rb = row_sum(dz);
+            const float rg = row_sum(dz * xh[T][r]);
+            if (j == T) {
+                keep_b[r] = rb;
+                keep_g[r] = rg;
+            }
+            const float gdz = ga[r] * dz;
+            s1 += gdz;
+            s2 = __builtin_fmaf(gdz, xh[T][r], s2);
+            acc[T][r] = gdz;
+        }
+    }
+    turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
+    turn.kg = keep_g;
+    turn.kb = keep_b;
+    const float m1 = group_sum(s1) * (1.0f / 256.0f);
+    const float m2 = group_sum(s2) * (1.0f / 256.0f);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        f32x4 dy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float da = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
+            dy[r] = xh[T][r] > shift ? da : 0.f;
+            act[4 * T + r] = dy[r];
+        }
+        *(f32x4*)(dy_row + T * 16) = dy;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* const ws = a.train_workspace;
+    float* const gamma = (float*)(smem + kRingBytes);
+    float* const gb = gamma + kGammaFloats;
+
+    // gamma of the ten LayerNorms (the backward needs neither bias nor beta: the ReLU gate comes from the
+    // saved a_hat), [L][g][T][r] as in the forward's small image
+    for (int i = threadIdx.x; i < kGammaFloats; i += 256)
+        gamma[i] = a.packed[kLegacyBlobFloats + (i / kHidden) * kLegacySmallPerLayer + kHidden + (i % kHidden)];
+    for (int i = threadIdx.x; i < kLGbFloats; i += 256) gb[i] = 0.f;
+
+    LBwdPipe pipe;
+    pipe.init(a.packed + kLegacyBwdOffset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    // one (padded ray, chunk) item per wave, as in the main network's data gradient
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;
+        const int64_t sp = tile * 16 + j;
+        const float* const xbase = ws + sp * kHidden + 4 * g;         // + L.xhat[l]: this lane's a_hat row
+        float* const dybase = ws + sp * kHidden + 4 * g;              // + L.dy[l]
+        const float* const stat = ws + sp;                            // + L.rstd[l] / L.shift[l]
+        // dL/d(density, r, g, b) of this sample: k slots (g 0, r 0..3) of BOTH head stages (the transposed
+        // head images carry zeros in the slots that are not theirs; lane groups 1..3 read zero columns)
+        const float* const dhead = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+        f32x4 xh[16];
+        float rstd, shift;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * 16);
+        rstd = stat[ba.L.rstd[9]];
+        shift = stat[ba.L.shift[9]];
+        // ---- color head: dX'_9 = Wc^T d(color) ----
+#pragma unroll
+        for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const f32x4 dh[1] = {*(const f32x4*)dhead};
+            layer_wide_v4<1>(pipe, acc, dh);
+        }
+        // ---- L9, L8: LayerNorm / ReLU backward, then dX = W^T dY (hidden columns) ----
+#pragma unroll 1
+        for (int l = 9; l >= 8; --l) {
+            relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
+                                gb + l * 2 * kHidden, turn);
+#pragma unroll
+            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            layer_wide<16>(pipe, acc, act,
+                           LegacyHook{turn, xbase + ba.L.xhat[l - 1], stat + ba.L.rstd[l - 1],
+                                      stat + ba.L.shift[l - 1], xh, rstd, shift});
+        }
+        // ---- density head joins: dX'_7 += Wd^T d(density) ----
+        {
+            const f32x4 dh[1] = {*(const f32x4*)dhead};
+            layer_wide_v4<1>(pipe, acc, dh);
+        }
+        // ---- L7 .. L1 (L4: hidden columns only, the encodings take no gradient) ----
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {
+            relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
+                                gb + l * 2 * kHidden, turn);
+#pragma unroll
+            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            layer_wide<16>(pipe, acc, act,
+                           LegacyHook{turn, xbase + ba.L.xhat[l - 1], stat + ba.L.rstd[l - 1],
+                                      stat + ba.L.shift[l - 1], xh, rstd, shift});
+        }
+        relu_layer_norm_bwd(gamma, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[0], gb, turn);
+        // layer 0's partials: no 4-stage loop follows inside this item (the next item opens with the
+        // one-stage color head), so the four waves take their turns here, a barrier apart
+        for (int t = 0; t < kWavesPerWg; ++t) {
+            __syncthreads();
+            turn(t);
+        }
+        turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kLGbFloats + i] = gb[i];
+}
+
+// All 14 products in ONE launch: job = blockIdx.x / splits, heavy (256 x 256) blocks first.
+__global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_kernel(const LBwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kLSlabFloats, nullptr, 0};
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kLegacyBlobFloats;            // [layer][bias | gamma | beta][256]
+    if (job < kHiddenJobs) {
+        // wide layer l = job + 1: dY_l against x'_{l-1} = gamma_{l-1} a_hat_{l-1} + beta_{l-1}
+        const int l = job + 1;
+        wgrad_body_ring<ShapeHid, kInputAffine>(jb, smem, ws + ba.L.dy[l], ws + ba.L.xhat[l - 1],
+                                                small + (l - 1) * kLegacySmallPerLayer,
+                                                kLSlabHid + job * kHidden * kHidden, kLSlabB + l * kHidden);
+    } else if (job < kHiddenJobs + 3) {
+        // the encoding columns: L0 x position, L4 x position, L8 x direction (only L0's bias sums are read)
+        const int e = job - kHiddenJobs;
+        const int l = e == 0 ? 0 : (e == 1 ? 4 : 8);
+        wgrad_body_ring<ShapeEnc, kInputRaw>(jb, smem, ws + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
+                                             kLSlabEnc + e * kHidden * kEncPad, e == 0 ? kLSlabB : kLSlabSpare);
+    } else {
+        // the heads: rows (d density, d r, d g, d b, 0 ..) against x'_7 (density: row 0) or x'_9 (color: rows 1..3)
+        const int h = job - kHiddenJobs - 3;
+        const int l = h == 0 ? 7 : 9;
+        wgrad_body_ring<ShapeL5, kInputAffine>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[l],
+                                               small + l * kLegacySmallPerLayer, kLSlabHead + h * kOutPad * kHidden,
+                                               kLSlabB + kWide * kHidden + h * kOutPad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic reduction of the partials into the flat gradient vector
+// ---------------------------------------------------------------------------------------------
+constexpr int kReduceThreads = 256;
+constexpr int kReduceDirectBlocks = (kLegacyGradElements + kReduceThreads - 1) / kReduceThreads;
+constexpr int kReduceGbBlocks = kLGbFloats / 4;                    // one wave per gamma / beta element
+
+__device__ __forceinline__ void legacy_locate(int e, int& tensor, int& idx) {
+    tensor = 0;
+    int off = 0;
+    for (;;) {
+        const int n = legacy_tensor_elements(tensor);
+        if (e < off + n) break;
+        off += n;
+        ++tensor;
+    }
+    idx = e - off;
+}
+
+__global__ void nerf_legacy_grad_reduce_kernel(const LBwdArgs ba) {
+    if ((int)blockIdx.x >= kReduceDirectBlocks) {
+        // gamma / beta: partials come one per data-gradient workgroup; one wave per element
+        const int lane = threadIdx.x & 63;
+        const int ge = ((int)blockIdx.x - kReduceDirectBlocks) * 4 + (threadIdx.x >> 6);    // [layer][gamma|beta][256]
+        const int l = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
+        const float* p = ba.gb_partial + ge;
+        float sum = 0.f;
+        for (int q = lane; q < ba.data_grid; q += 64) sum += p[(int64_t)q * kLGbFloats];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) ba.grad[legacy_grad_offset(wide_param(l) + 2 + which) + idx] = sum;
+        return;
+    }
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kLegacyGradElements) return;
+    int tensor, idx;
+    legacy_locate(e, tensor, idx);
+    int so;
+    if (tensor == kDensityW) so = kLSlabHead + idx;                                        // row 0 of the density job
+    else if (tensor == kDensityB) so = kLSlabB + kWide * kHidden;
+    else if (tensor == kColorW) so = kLSlabHead + kOutPad * kHidden + (1 + idx / kHidden) * kHidden + idx % kHidden;
+    else if (tensor == kColorB) so = kLSlabB + kWide * kHidden + kOutPad + 1 + idx;
+    else {
+        const int w = tensor < kDensityW ? tensor : tensor - 2;
+        const int l = w / 4, which = w % 4;
+        if (which >= 2) return;                   // gamma / beta: the blocks behind
+        if (which == 1) so = kLSlabB + l * kHidden + idx;
+        else {
+            const int K = wide_inputs(l), row = idx / K, col = idx % K;
+            if (l == 0) so = kLSlabEnc + row * kEncPad + encoding_column(col, kPosPerGroup);
+            else if (col < kHidden) so = kLSlabHid + (l - 1) * kHidden * kHidden + row * kHidden + col;
+            else if (l == 4) so = kLSlabEnc + kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kPosPerGroup);
+            else so = kLSlabEnc + 2 * kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kDirPerGroup);
+        }
+    }
+    ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kLSlabFloats);
+}
+
+int choose_splits(int64_t n_tiles) {
+    int64_t s = n_tiles / 8;
+    if (s < 1) s = 1;
+    if (s > kMaxSplits) s = kMaxSplits;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nerf_hip_legacy_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
+    if (n_rays <= 0 || num_samples < 2) return 0;
+    return ((size_t)kMaxSplits * kLSlabFloats + (size_t)kMaxDataGrid * kLGbFloats) * sizeof(float);
+}
+
+int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void* stream) {
+    if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: null args");
+    const NerfHipRenderArgs& a = args->fwd.render;
+    if (args->grad == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: grad is null");
+    if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
+        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)kLegacyGradElements * sizeof(float),
+                                                     (hipStream_t)stream), "legacy_render_backward memset");
+    if (args->scratch == nullptr || args->d_rgb == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: scratch / d_rgb is null");
+    if (a.train_workspace == nullptr || a.packed == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: forward was not a training forward");
+    if (a.n_rays < 0 || a.num_samples < 2 || a.num_samples > 4096)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: n_rays / num_samples out of range");
+    if (a.precision != NERF_HIP_PRECISION_FP32)
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "legacy_render_backward: fp32 arithmetic only");
+    hipStream_t st = (hipStream_t)stream;
+
+    LBwdArgs ba;
+    ba.a = a;
+    ba.d_rgb = args->d_rgb;
+    ba.samples = a.num_samples;
+    ba.chunks = (a.num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
+    ba.L = make_legacy_train_layout(a.n_rays, ba.chunks);
+    ba.groups = ba.L.mp / 16 / kWavesPerWg;                 // (padded ray, chunk) items / 4 waves
+    const int64_t slots = ba.L.mp / 16 / ba.chunks;         // padded rays
+    ba.grad = args->grad;
+    ba.n_tiles = ba.L.mp / kKs;
+    ba.splits = choose_splits(ba.n_tiles);
+    ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
+    ba.slabs = args->scratch;
+    ba.gb_partial = args->scratch + (size_t)kMaxSplits * kLSlabFloats;
+
+    int device = 0, cus = 0;
+    int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
+    if (rc) return rc;
+    rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
+                                "hipDeviceGetAttribute");
+    if (rc) return rc;
+    static unsigned done_data = 0, done_wgrad = 0;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_bwd_data_kernel, kLBwdLdsBytes, device, &done_data);
+    if (rc) return rc;
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_wgrad_kernel, kRingSlots * kRingSlotBytes, device,
+                                         &done_wgrad);
+    if (rc) return rc;
+    int64_t grid = (int64_t)cus * 2;
+    if (grid > ba.groups) grid = ba.groups;
+    if (grid > kMaxDataGrid) grid = kMaxDataGrid;
+    ba.data_grid = (int)grid;
+
+    hipLaunchKernelGGL(nerf_legacy_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
+                       dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(nerf_legacy_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes, st, ba);
+    hipLaunchKernelGGL(nerf_legacy_wgrad_kernel, dim3(ba.splits * kWgradJobs), dim3(256), kRingSlots * kRingSlotBytes,
+                       st, ba);
+    hipLaunchKernelGGL(nerf_legacy_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks),
+                       dim3(kReduceThreads), 0, st, ba);
+    return nerf_common::check_hip(hipGetLastError(), "legacy_render_backward launch");
+}
+
+}  // extern "C"

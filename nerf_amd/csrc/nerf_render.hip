@@ -664,30 +664,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
 // Compositing of the training forward: one wave per ray over the saved network outputs.
 __global__ __launch_bounds__(256) void nerf_composite_fwd_kernel(const KernelArgs ka) {
-    const NerfHipRenderArgs& a = ka.a;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15;
-    const int64_t local = (int64_t)blockIdx.x * kWavesPerWg + wave;
-    if (local >= a.n_rays) return;
-    const int P = ka.intervals;
-    float* const ws = a.train_workspace;
-    RayAccum racc;
-    racc.reset();
-    for (int c = 0; c < ka.chunks; ++c) {
-        const int s = c * kSamplesPerWave + j;
-        const bool ok = s < P;
-        const int64_t tile = local * ka.chunks + c;
-        const int64_t sp = tile * 16 + j;
-        f32x4 out[4];
-        const float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
-        float* comp = ws + ka.save.comp + sp * 4;
-        const float dist = comp[2];
-        const float w = composite_chunk<true>(a, P, local, s, ok, lane, out, dist, racc, comp);
-        if (a.out_weights != nullptr && ok && lane < 16) a.out_weights[local * P + s] = w;
-    }
-    store_ray(a, local, true, lane, racc);
+    composite_fwd_body(ka.a, ka.intervals, ka.chunks, ka.save.out, ka.save.comp);
 }
 
 // ---------------------------------------------------------------------------------------------

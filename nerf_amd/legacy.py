@@ -15,7 +15,15 @@ PARITY UNPINNED.  What the checkpoint cannot settle — activation (ReLU), frequ
 concatenation order ([hidden, encoding]), normalised view directions — are stated choices that
 ``oracle/legacy_oracle.py`` restates on the CPU and SURVEY.md's probe found to render the Lego
 scene; they are constructor keywords.  Everything render_rays computes is ONE fused HIP launch
-(``nerf_hip_legacy_render_forward``, nerf_amd/csrc/nerf_legacy.hip); inference only.
+(``nerf_hip_legacy_render_forward``, nerf_amd/csrc/nerf_legacy.hip).
+
+Training (the notebook's loop, cell 8: ``((pixels - batch['pixels']) ** 2).mean().backward()``, Adam):
+with gradients enabled ``render_rays`` goes through ``LegacyRenderRaysFunction``, whose backward is
+``nerf_hip_legacy_render_backward`` (nerf_amd/csrc/nerf_legacy_backward.hip): the 44 parameter gradients as
+views of ONE flat vector in ``parameters()`` order (``model.last_flat_grad``, what the data-parallel
+all-reduce runs on in place).  The training arithmetic is fp32 MFMA (forward, data gradient) and bf16
+triples (weight gradient), i.e. exact-fp32 products throughout; ``precision`` only selects the arithmetic of
+inference launches.
 """
 import ctypes
 import math
@@ -38,18 +46,74 @@ def _block(first_inputs, layers):
     return nn.Sequential(*mods)
 
 
+class LegacyRenderRaysFunction(torch.autograd.Function):
+    """rgb [N,3] = f(parameters): forward = the training instantiation of the fused kernel (it also saves
+    the encodings, the LayerNorm statistics and a_hat of every wide layer, the head outputs), backward = four
+    HIP launches that leave the flat gradient (nerf_hip_legacy_render_backward).  Inputs after
+    ``density_noise_std`` are the 44 parameters in the kernels' order.  Rays and draws take no gradient."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, near, far, num_samples, u, noise, density_noise_std, *params):
+        lib = _lib.lib()
+        n_rays, device = rays_o.shape[0], rays_o.device
+        ws_bytes = lib.nerf_hip_legacy_train_workspace_bytes(n_rays, num_samples)
+        workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
+        rgb, _, _ = model._launch(n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, u=u,
+                                  noise=noise, density_noise_std=density_noise_std, train_workspace=workspace)
+        if getattr(model, "keep_workspace", False):      # debugging / stage-parity tests only
+            model.last_workspace = workspace
+        ctx.model = model
+        ctx.call = (rays_o, rays_d, near, far, num_samples, u, noise, density_noise_std)
+        ctx.workspace = workspace
+        ctx.packed = model._last_packed               # the image this forward used (its own buffer)
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(rgb)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        lib = _lib.lib()
+        model = ctx.model
+        (rgb,) = ctx.saved_tensors
+        rays_o, rays_d, near, far, num_samples, u, noise, std = ctx.call
+        n_rays, device = rays_o.shape[0], rays_o.device
+        d_rgb = d_rgb.contiguous()
+        args = _lib.LegacyBackwardArgs()
+        model._fill_args(args.fwd, n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, u=u,
+                         noise=noise, density_noise_std=std, packed=ctx.packed, rgb=rgb,
+                         train_workspace=ctx.workspace, precision="fp32")
+        grad = torch.empty(lib.nerf_hip_legacy_grad_elements(), dtype=torch.float32, device=device)
+        scratch = model._scratch(lib.nerf_hip_legacy_backward_scratch_bytes(n_rays, num_samples), device)
+        args.d_rgb, args.grad, args.scratch = _lib.ptr(d_rgb), _lib.ptr(grad), _lib.ptr(scratch)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nerf_hip_legacy_render_backward(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_legacy_render_backward")
+        ctx.workspace = None
+        grads, off = [], 0
+        for shape in ctx.shapes:                  # views of the flat vector, parameters() order
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(grad[off:off + n].view(shape))
+            off += n
+        model.last_flat_grad = grad
+        return (None,) * 9 + tuple(grads)
+
+
 class LegacyNeRF8x256(nn.Module):
     def __init__(self, normalize_position=6.0, multiplier=math.pi, normalize_directions=True):
         super().__init__()
         self.normalize_position = float(normalize_position)
         self.multiplier = float(multiplier)
         self.normalize_directions = bool(normalize_directions)
-        # the checkpoint's tree: block_0.{0,3,6,9} Linear, .{2,5,8,11} LayerNorm, slots 1,4,7,10 parameter-less
-        self.density = nn.Linear(256, 1)
-        self.color = nn.Linear(256, 3)
-        self.block_0 = _block(60, 4)
-        self.block_1 = _block(256 + 60, 4)
-        self.block_2 = _block(256 + 36, 2)
+        # the checkpoint's tree: block_0.{0,3,6,9} Linear, .{2,5,8,11} LayerNorm, slots 1,4,7,10 parameter-less.
+        # Registered in the kernels' tensor order (nerf_legacy_layout.h) so that parameters() IS that order:
+        # the flat gradient the backward writes then aliases every p.grad in optimiser / all-reduce order.
+        # (Creation order below keeps the seeded default initialisation of earlier rounds: density, color first.)
+        density, color = nn.Linear(256, 1), nn.Linear(256, 3)
+        block_0, block_1, block_2 = _block(60, 4), _block(256 + 60, 4), _block(256 + 36, 2)
+        self.block_0, self.block_1, self.density, self.block_2, self.color = block_0, block_1, density, block_2, color
         self._packed = None
         self._packed_key = None
         self._tables = {}
@@ -75,9 +139,10 @@ class LegacyNeRF8x256(nn.Module):
                       self.block_2[slot + 2].weight, self.block_2[slot + 2].bias]
         return order + [self.color.weight, self.color.bias]
 
-    def packed_parameters(self):
+    def packed_parameters(self, fresh=False):
         """Re-packed on every call (one small launch), like nerf_amd.model.NeRF.packed_parameters:
-        version counters miss fused-optimiser and ``p.data`` updates."""
+        version counters miss fused-optimiser and ``p.data`` updates.  ``fresh``: into a buffer of its
+        own (a training forward: its backward reads the image later)."""
         params = self._param_list()
         dev = params[0].device
         for p in params:
@@ -85,13 +150,17 @@ class LegacyNeRF8x256(nn.Module):
         lib = _lib.lib()
         keep = [p.detach().contiguous() for p in params]
         ptrs = (ctypes.c_void_p * _lib.NUM_LEGACY_PARAM_TENSORS)(*[p.data_ptr() for p in keep])
-        if self._packed is None or self._packed.device != dev:
-            self._packed = torch.empty(lib.nerf_hip_legacy_packed_bytes() // 4, dtype=torch.float32, device=dev)
+        packed = self._packed
+        if fresh or packed is None or packed.device != dev:
+            packed = torch.empty(lib.nerf_hip_legacy_packed_bytes() // 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.nerf_hip_legacy_pack_weights(ptrs, _lib.ptr(self._packed), ctypes.c_void_p(stream)),
+            _lib.check(lib.nerf_hip_legacy_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
                        "nerf_hip_legacy_pack_weights")
-        return self._packed
+        if not fresh:
+            self._packed = packed
+        self._last_packed = packed
+        return packed
 
     def _check_f16x3_range(self):
         """The split-precision kernel holds 2^8 * w and 2^4 * (gamma * x_hat + beta) as f16 pairs
@@ -114,18 +183,11 @@ class LegacyNeRF8x256(nn.Module):
                                                dtype=torch.float32).to(device)
         return self._tables[key]
 
-    def _launch(self, n_rays, num_samples, device, near, far, *, rays_o=None, rays_d=None, cameras=None,
-                ray_begin=0, u=None, noise=None, density_noise_std=0.0, rgb=None, per_sample=False):
-        lib = _lib.lib()
-        packed = self.packed_parameters()
-        if rgb is None:
-            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
-        raw = weights = None
-        if per_sample:
-            raw = torch.empty(n_rays, num_samples, 4, dtype=torch.float32, device=device)
-            weights = torch.empty(n_rays, num_samples, dtype=torch.float32, device=device)
+    def _fill_args(self, args, n_rays, num_samples, device, near, far, *, rays_o=None, rays_d=None, cameras=None,
+                   ray_begin=0, u=None, noise=None, density_noise_std=0.0, packed=None, rgb=None, raw=None,
+                   weights=None, train_workspace=None, precision=None):
+        """Fill a NerfHipLegacyArgs block (include/nerf_hip.h) from tensors."""
         table = self._table(near, far, num_samples, device)
-        args = _lib.LegacyArgs()
         r = args.render
         r.rays_o, r.rays_d = _lib.ptr(rays_o), _lib.ptr(rays_d)
         if cameras is not None:
@@ -138,14 +200,39 @@ class LegacyNeRF8x256(nn.Module):
         r.density_noise_std = float(density_noise_std)
         r.packed, r.rgb = _lib.ptr(packed), _lib.ptr(rgb)
         r.out_raw, r.out_weights = _lib.ptr(raw), _lib.ptr(weights)
-        if self.precision not in _lib.PRECISIONS:
-            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
-        r.precision = _lib.PRECISIONS[self.precision]
-        if self.precision == "f16x3":
-            self._check_f16x3_range()
+        r.train_workspace = _lib.ptr(train_workspace)
+        r.precision = _lib.PRECISIONS[precision]
         args.normalize_position = self.normalize_position
         args.multiplier = self.multiplier
         args.normalize_directions = 1 if self.normalize_directions else 0
+
+    def _scratch(self, nbytes, device):
+        """Cached scratch buffer for the backward's partial slabs."""
+        cur = getattr(self, "_scratch_buf", None)
+        if cur is None or cur.numel() * 4 < nbytes or cur.device != device:
+            self._scratch_buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        return self._scratch_buf
+
+    def _launch(self, n_rays, num_samples, device, near, far, *, rays_o=None, rays_d=None, cameras=None,
+                ray_begin=0, u=None, noise=None, density_noise_std=0.0, rgb=None, per_sample=False,
+                train_workspace=None):
+        lib = _lib.lib()
+        packed = self.packed_parameters(fresh=train_workspace is not None)
+        if rgb is None:
+            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
+        raw = weights = None
+        if per_sample:
+            raw = torch.empty(n_rays, num_samples, 4, dtype=torch.float32, device=device)
+            weights = torch.empty(n_rays, num_samples, dtype=torch.float32, device=device)
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
+        precision = "fp32" if train_workspace is not None else self.precision
+        if precision == "f16x3":
+            self._check_f16x3_range()
+        args = _lib.LegacyArgs()
+        self._fill_args(args, n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, cameras=cameras,
+                        ray_begin=ray_begin, u=u, noise=noise, density_noise_std=density_noise_std, packed=packed,
+                        rgb=rgb, raw=raw, weights=weights, train_workspace=train_workspace, precision=precision)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nerf_hip_legacy_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
@@ -168,6 +255,11 @@ class LegacyNeRF8x256(nn.Module):
             noise = torch.randn(n_rays, num_samples, dtype=torch.float32, device=dev)
         u = None if u is None else u.detach().reshape(n_rays, num_samples).contiguous()
         noise = None if noise is None else noise.detach().reshape(n_rays, num_samples).contiguous()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad and not per_sample:
+            rgb = LegacyRenderRaysFunction.apply(self, flat_o, flat_d, float(near), float(far), num_samples, u, noise,
+                                                 float(density_noise_std), *self._param_list())
+            return rgb.reshape(*lead, 3)
         rgb, raw, weights = self._launch(n_rays, num_samples, dev, near, far, rays_o=flat_o, rays_d=flat_d,
                                          u=u, noise=noise, density_noise_std=density_noise_std,
                                          per_sample=per_sample)

@@ -85,9 +85,13 @@ def load_pickled_scene(path, device, camera_focal_length, camera_ccd_width):
 
 
 class Trainer:
+    """``model``: a generation-C ``NeRF`` (default) or a ``LegacyNeRF8x256`` — the network of the notebook
+    and of examples/nerf.pth, trained the notebook's way (examples/example.ipynb cell 8): explicit
+    ``near`` / ``far`` planes, ``render_rays`` returning [N, 3], the same MSE / Adam / PSNR recipe."""
+
     def __init__(self, images, poses, focal_length, logging_dir=None, batch_size=1024,
                  learning_rate=1e-4, num_samples_per_ray=64, density_noise_std=1.0, log_interval=1000,
-                 segmentation=None, model=None, seed=0, rng="torch", graph=False):
+                 segmentation=None, model=None, seed=0, rng="torch", graph=False, near=2.0, far=6.0):
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if self.distributed else 0
         self.world = dist.get_world_size() if self.distributed else 1
@@ -103,6 +107,11 @@ class Trainer:
             torch.manual_seed(seed)
             model = NeRF(focal_length=focal_length).to(device)
         self.model = model
+        from .legacy import LegacyNeRF8x256
+        self.legacy = isinstance(model, LegacyNeRF8x256)
+        self.near, self.far = float(near), float(far)
+        if self.legacy and rng != "torch":
+            raise ValueError("the legacy network draws with torch's generator only (rng='torch')")
         self.model.rng = rng
         # draws: with rng="torch" the stratified / noise draws come from torch's generator, so give
         # every rank its own stream (seed + rank); the in-kernel Philox path folds the rank into its
@@ -150,16 +159,32 @@ class Trainer:
             with open(os.path.join(self.logging_dir, "params.json"), "w") as f:
                 json.dump(params, f, indent=4)
 
+    def _draw(self, n, device, generator):
+        """The reference's draws in the reference's order (rand, then randn: nerf/model.py:432, :652); the
+        legacy network evaluates S points per ray, generation C S - 1 intervals."""
+        u = torch.rand(n, self.num_samples, dtype=torch.float32, device=device, generator=generator)
+        shape = (n, self.num_samples) if self.legacy else (n, self.num_samples - 1, 1)
+        return u, torch.randn(*shape, dtype=torch.float32, device=device, generator=generator)
+
+    def _render(self, rays_o, rays_d, u, noise):
+        """Pixels [n, 3] of a training batch (``u`` / ``noise`` None: drawn by the renderer itself)."""
+        if noise is not None and self.density_noise_std == 0.0:
+            noise = None
+        if self.legacy:
+            return self.model.render_rays(rays_o, rays_d, self.near, self.far, self.num_samples,
+                                          randomly_sample=True, density_noise_std=self.density_noise_std,
+                                          u=u, noise=noise)
+        pixels, _ = self.model.render_rays(rays_o, rays_d, self.num_samples, randomly_sample=True,
+                                           density_noise_std=self.density_noise_std, u=u, noise=noise)
+        return pixels[:, 0]                               # the single stage (train_conditional_nerf.py:132)
+
     # ---- HIP-graph path ---------------------------------------------------------------------------
     def _graph_body(self, o, d, pix):
         n, dev = o.shape[0], o.device
-        u = torch.rand(n, self.num_samples, dtype=torch.float32, device=dev)           # graph-safe default
-        noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32, device=dev)   # generator
+        u, noise = self._draw(n, dev, None)               # graph-safe default generator
         self.last_draws = (u, noise)                      # (static tensors of the graph once captured)
-        pixels, _ = self.model.render_rays(o, d, self.num_samples, randomly_sample=True,
-                                           density_noise_std=self.density_noise_std, u=u,
-                                           noise=noise if self.density_noise_std != 0.0 else None)
-        loss = ((pixels - pix.unsqueeze(1)) ** 2).sum() / max(3 * n, 1)
+        pixels = self._render(o, d, u, noise)
+        loss = ((pixels - pix) ** 2).sum() / max(3 * n, 1)
         loss.backward()
         if not self.distributed:
             self.optimizer.step()
@@ -212,7 +237,7 @@ class Trainer:
         if self.distributed:
             self.reduce(self._static_flat, n / max(int(batch.get("global_n", n * self.world)), 1))
             self.optimizer.step()
-        if self.model.train_precision == "f16x3" and self.iteration % 64 == 0:
+        if getattr(self.model, "train_precision", "fp32") == "f16x3" and self.iteration % 64 == 0:
             self.model.check_split_precision_range()      # the replay runs no host code
         return self._static_loss
 
@@ -226,18 +251,12 @@ class Trainer:
         if self.model.rng == "torch":
             # the reference's draws in the reference's order (rand, then randn: nerf/model.py:432, :652):
             # from this rank's own generator when data-parallel, else from torch's default one
-            gen = self.draws if self.distributed else None
-            u = torch.rand(n, self.num_samples, dtype=torch.float32, device=batch["rays_o"].device,
-                           generator=gen)
-            noise = torch.randn(n, self.num_samples - 1, 1, dtype=torch.float32,
-                                device=batch["rays_o"].device, generator=gen)
+            u, noise = self._draw(n, batch["rays_o"].device, self.draws if self.distributed else None)
         self.last_draws = (u, noise)                      # what this step rendered with (None: in-kernel Philox)
-        pixels, _ = self.model.render_rays(batch["rays_o"], batch["rays_d"], self.num_samples,
-                                           randomly_sample=True,
-                                           density_noise_std=self.density_noise_std, u=u, noise=noise)
+        pixels = self._render(batch["rays_o"], batch["rays_d"], u, noise)
         self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
         # sum / count instead of mean(): an empty shard (tail of an epoch) gives 0, not NaN
-        loss = ((pixels - batch["pixels"].unsqueeze(1)) ** 2).sum() / max(3 * n, 1)
+        loss = ((pixels - batch["pixels"]) ** 2).sum() / max(3 * n, 1)
         loss.backward()
         if self.distributed:
             self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
@@ -245,11 +264,14 @@ class Trainer:
         return loss.detach()
 
     def evaluate(self):
+        cam_o, cam_r = self.test_pose[..., :3, 3].contiguous(), self.test_pose[..., :3, :3].contiguous()
         with torch.no_grad():
-            render, _ = self.model.render_image(self.test_pose[..., :3, 3].contiguous(),
-                                                self.test_pose[..., :3, :3].contiguous(),
-                                                self.image_h, self.image_w, self.focal_length,
-                                                self.num_samples)
+            if self.legacy:                               # the notebook's call (cell 8)
+                render = self.model.render_image(cam_o, cam_r, self.image_h, self.image_w, self.focal_length,
+                                                 self.near, self.far, self.num_samples)
+            else:
+                render, _ = self.model.render_image(cam_o, cam_r, self.image_h, self.image_w,
+                                                    self.focal_length, self.num_samples)
         value = psnr(render, self.test_image)
         self.psnrs.append(value.cpu().numpy())
         self.iternums.append(self.iteration)

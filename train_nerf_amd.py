@@ -25,14 +25,17 @@ if __name__ == "__main__":
     ap.add_argument("--camera-focal-length", type=float, default=50.0)
     ap.add_argument("--camera-ccd-width", type=float, default=36.0)
     ap.add_argument("--batch-size", type=int, default=1024)
-    ap.add_argument("--normalize-position", type=float, default=20.0)      # accepted, unused (gen. B)
+    ap.add_argument("--normalize-position", type=float, default=20.0)      # legacy8x256: positions / this
     ap.add_argument("--learning-rate", type=float, default=0.0001)
-    ap.add_argument("--near-plane", type=float, default=0.0)               # accepted, unused (gen. B)
-    ap.add_argument("--far-plane", type=float, default=20.0)               # accepted, unused (gen. B)
+    ap.add_argument("--near-plane", type=float, default=0.0)               # legacy8x256: sample range
+    ap.add_argument("--far-plane", type=float, default=20.0)               # (generation C: implicit, unused)
     ap.add_argument("--num-samples-per-ray", type=int, default=64)
     ap.add_argument("--density-noise-std", type=float, default=1.0)
     ap.add_argument("--log-interval", type=int, default=1000)
     ap.add_argument("--max-iterations", type=int, default=None)
+    # mipnerf: the network of nerf/model.py as shipped (generation C).  legacy8x256: the 8 x 256 sin/cos
+    # network of examples/nerf.pth and of the notebook (NeRF(normalize_position=6.0), near 2, far 6)
+    ap.add_argument("--network", choices=("mipnerf", "legacy8x256"), default="mipnerf")
     ap.add_argument("--rng", choices=("torch", "philox"), default="philox")
     # arithmetic of the MLP in the held-out renders ...
     ap.add_argument("--precision", choices=("fp32", "f16x3"), default="fp32")
@@ -58,12 +61,19 @@ if __name__ == "__main__":
     else:
         images, poses, focal = T.load_pickled_scene(args.data, device, args.camera_focal_length,
                                                     args.camera_ccd_width)
+    model = None
+    if args.network == "legacy8x256":
+        from nerf_amd.legacy import LegacyNeRF8x256
+        torch.manual_seed(0)
+        model = LegacyNeRF8x256(normalize_position=args.normalize_position).to(device)
+        args.rng = "torch"
     run = T.Trainer(images, poses, focal, logging_dir=args.logging_dir, batch_size=args.batch_size,
                     learning_rate=args.learning_rate, num_samples_per_ray=args.num_samples_per_ray,
                     density_noise_std=args.density_noise_std, log_interval=args.log_interval,
-                    rng=args.rng, graph=args.graph)
+                    rng=args.rng, graph=args.graph, model=model, near=args.near_plane, far=args.far_plane)
     run.model.precision = args.precision
-    run.model.train_precision = args.train_precision
+    if args.network == "mipnerf":
+        run.model.train_precision = args.train_precision
     run.write_params(vars(args))
     run.fit(epochs=args.epochs, max_iterations=args.max_iterations)
     if run.rank == 0 and run.psnrs:
