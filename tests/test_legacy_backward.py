@@ -162,17 +162,8 @@ def test_notebook_training_step_vs_oracle():
         assert (p.detach().cpu() - ref[k].detach()).abs().max() <= 2.1e-4, k
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("graph", [False, True])
-def test_forty_training_steps_on_the_checkpoints_scene_track_the_oracle(graph):
-    """Scene: views of the reference's trained Lego weights (fixture G9), rendered by the legacy kernel.  A
-    freshly initialised network is trained on them for 40 steps of the notebook's recipe by
-    nerf_amd.trainer.Trainer (eagerly, and as one HIP-graph replay per step); the oracle's CPU run sees the
-    same rays, targets and draws.  Loss trajectory step by step, held-out PSNR within 0.01 dB."""
-    from nerf_amd import trainer as T
-    from nerf_amd.legacy import LegacyNeRF8x256
-    dev = torch.device("cuda:0")
-    steps, batch, S, lr, size, views = 40, 256, 32, 5e-4, 16, 6
+def lego_scene(dev, size=16, views=6):
+    """Views of the reference's trained Lego weights (fixture G9), rendered by the legacy kernel."""
     focal = 138.88887889922103 * size / 100.0            # tiny_nerf's focal length scaled to the frame
     teacher = make_model(dev, checkpoint()[0])
     gen = torch.Generator().manual_seed(4)
@@ -188,42 +179,117 @@ def test_forty_training_steps_on_the_checkpoints_scene_track_the_oracle(graph):
         images = teacher.render_image(poses[:, :3, 3].contiguous(), poses[:, :3, :3].contiguous(), size, size,
                                       focal, 2.0, 6.0, 64)
     assert float(images.mean()) > 0.02                   # the bulldozer is in the frames
+    return images, poses, focal
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_forty_training_steps_on_the_checkpoints_scene_track_the_oracle(graph):
+    """Scene: views of the reference's trained Lego weights (fixture G9).  A freshly initialised network is
+    trained on them for 40 steps of the notebook's recipe (examples/example.ipynb cell 8) by
+    nerf_amd.trainer.Trainer — eagerly, and as one HIP-graph replay per step; the oracle's CPU run sees the same
+    rays, targets and draws.  This network's training is ILL-CONDITIONED in fp32 (ReLU gates of a fresh
+    initialisation sit within rounding of zero: the oracle's own fp32 gradients differ from their fp64 evaluation
+    by up to 1.6e-2 of a tensor's largest on these batches, tests/tools/legacy_traj_probe.py), so two runs that
+    differ by rounding drift apart; the bound is therefore the rule of the gradient tests applied to
+    trajectories: the HIP run must stay as close to the fp32 oracle as 8 x the fp32 oracle stays to the SAME
+    oracle in fp64 (loss step by step; held-out PSNR, train_conditional_nerf.py:152-153, at the end)."""
+    from nerf_amd import trainer as T
+    dev = torch.device("cuda:0")
+    steps, batch, S, lr, size = 40, 256, 32, 5e-4, 16
+    images, poses, focal = lego_scene(dev, size)
     params0 = L.init_params(seed=5)
     model = make_model(dev, params0)
     run = T.Trainer(images, poses, focal, batch_size=batch, learning_rate=lr, num_samples_per_ray=S,
                     density_noise_std=1.0, log_interval=10 ** 9, model=model, seed=11, graph=graph, near=2.0, far=6.0)
     assert run.legacy
-    ref = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
-    ref_opt = torch.optim.Adam([ref[k] for k in L.state_dict_keys()], lr=lr)
+    refs, opts = {}, {}
+    for dtype in (torch.float32, torch.float64):
+        refs[dtype] = {k: v.to(dtype).clone().requires_grad_(True) for k, v in params0.items()}
+        opts[dtype] = torch.optim.Adam([refs[dtype][k] for k in L.state_dict_keys()], lr=lr)
     gen = torch.Generator().manual_seed(6)
-    gpu_losses, cpu_losses = [], []
+    losses = {"hip": [], torch.float32: [], torch.float64: []}
     for _ in range(steps):
         idx = torch.randint(0, len(run.dataset), (batch,), generator=gen)
         b = run.dataset.gather(idx.to(dev))
         run.iteration += 1
         loss = run.train_step(b)
         u, noise = (t.detach().cpu().clone() for t in run.last_draws)
-        gpu_losses.append(float(loss))
-        pixels = L.render_rays(ref, CFG, b["rays_o"].cpu(), b["rays_d"].cpu(), 2.0, 6.0, S, u=u,
-                               noise=noise.unsqueeze(-1), density_noise_std=1.0)
-        ref_loss = ((pixels - b["pixels"].cpu()) ** 2).mean()
-        ref_opt.zero_grad()
-        ref_loss.backward()
-        ref_opt.step()
-        cpu_losses.append(float(ref_loss.detach()))
+        losses["hip"].append(float(loss))
+        for dtype in refs:
+            pixels = L.render_rays(refs[dtype], CFG, b["rays_o"].cpu().to(dtype), b["rays_d"].cpu().to(dtype), 2.0, 6.0,
+                                   S, u=u.to(dtype), noise=noise.unsqueeze(-1).to(dtype), density_noise_std=1.0)
+            ref_loss = ((pixels - b["pixels"].cpu().to(dtype)) ** 2).mean()
+            opts[dtype].zero_grad()
+            ref_loss.backward()
+            opts[dtype].step()
+            losses[dtype].append(float(ref_loss.detach()))
     if graph:
         assert run._graph is not None and run._graph_rays == batch
-    gl, cl = torch.tensor(gpu_losses), torch.tensor(cpu_losses)
+    gl, cl, cl64 = (torch.tensor(losses[k], dtype=torch.float64) for k in ("hip", torch.float32, torch.float64))
     assert cl[-10:].mean() < 0.8 * cl[:5].mean()         # it does train
-    assert ((gl - cl).abs() <= 2e-3 * cl + 1e-7).all(), (gl - cl).abs().max()
+    assert ((gl[:3] - cl[:3]).abs() <= 1e-5 * cl[:3]).all()              # identical before rounding drift sets in
+    drift = torch.cummax((cl - cl64).abs(), dim=0).values               # what rounding alone does to this trajectory
+    assert ((gl - cl).abs() <= 2e-3 * cl + 8 * drift).all(), ((gl - cl).abs() / (2e-3 * cl + 8 * drift)).max()
     run.iteration = steps
     psnr_gpu = run.evaluate()
+    cam_o, cam_r = poses[-1:, :3, 3].cpu(), poses[-1:, :3, :3].cpu()
+    rays_o, rays_d = O.image_rays(cam_o, cam_r, size, size, focal)
+    psnr_cpu = {}
     with torch.no_grad():
-        cam_o, cam_r = poses[-1:, :3, 3].cpu(), poses[-1:, :3, :3].cpu()
-        rays_o, rays_d = O.image_rays(cam_o, cam_r, size, size, focal)
-        ref_render = L.render_rays({k: v.detach() for k, v in ref.items()}, CFG, rays_o, rays_d, 2.0, 6.0, S)
-    psnr_cpu = float(O.psnr(ref_render.reshape(1, size, size, 3), images[-1:].cpu()))
-    print(f"[legacy, graph={graph}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, oracle {psnr_cpu:.4f} dB; "
-          f"max loss deviation {float((gl - cl).abs().max()):.2e}")
-    assert abs(psnr_gpu - psnr_cpu) <= 0.01
+        for dtype in refs:
+            render = L.render_rays({k: v.detach() for k, v in refs[dtype].items()}, CFG, rays_o.to(dtype),
+                                   rays_d.to(dtype), 2.0, 6.0, S)
+            psnr_cpu[dtype] = float(O.psnr(render.reshape(1, size, size, 3), images[-1:].cpu().to(dtype)))
+    spread = abs(psnr_cpu[torch.float32] - psnr_cpu[torch.float64])
+    print(f"[legacy, graph={graph}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, oracle fp32 "
+          f"{psnr_cpu[torch.float32]:.4f} dB, oracle fp64 {psnr_cpu[torch.float64]:.4f} dB; max loss deviation HIP-fp32 "
+          f"{float((gl - cl).abs().max()):.2e}, fp32-fp64 {float(drift[-1]):.2e}")
+    assert abs(psnr_gpu - psnr_cpu[torch.float32]) <= 0.01 + 8 * spread
+
+
+@pytest.mark.gpu
+def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameters():
+    """The conditioning-free version of the trajectory test: along the oracle's own 24-step training run on the
+    same scene, the HIP model is given the oracle's parameters before EVERY step; the loss must agree to 1e-5
+    relative at every step and, every eighth step, all 44 gradients within the rule of the gradient tests."""
+    from nerf_amd import trainer as T
+    dev = torch.device("cuda:0")
+    steps, batch, S, lr, size = 24, 256, 32, 5e-4, 16
+    images, poses, focal = lego_scene(dev, size)
+    data = T.PixelRayDataset(images[:-1], torch.zeros(5, size, size, dtype=torch.int64, device=dev), poses[:-1], focal)
+    params0 = L.init_params(seed=5)
+    model = make_model(dev, params0)
+    ref = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
+    ref_opt = torch.optim.Adam([ref[k] for k in L.state_dict_keys()], lr=lr)
+    gen = torch.Generator().manual_seed(6)
+    for step in range(steps):
+        idx = torch.randint(0, len(data), (batch,), generator=gen)
+        b = data.gather(idx.to(dev))
+        u, noise = torch.rand(batch, S, generator=gen), torch.randn(batch, S, 1, generator=gen)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                p.copy_(ref[k].detach().to(dev))
+        model.zero_grad(set_to_none=True)
+        pixels = model.render_rays(b["rays_o"], b["rays_d"], 2.0, 6.0, S, randomly_sample=True, density_noise_std=1.0,
+                                   u=u.to(dev), noise=noise[..., 0].to(dev))
+        loss = ((pixels - b["pixels"]) ** 2).mean()
+        loss.backward()
+        o, d, target = b["rays_o"].cpu(), b["rays_d"].cpu(), b["pixels"].cpu()
+
+        def loss_of(p, cast):
+            px = L.render_rays(p, CFG, cast(o), cast(d), 2.0, 6.0, S, u=cast(u), noise=cast(noise), density_noise_std=1.0)
+            return ((px - cast(target)) ** 2).mean()
+
+        ref_loss = loss_of(ref, lambda t: t)
+        ref_opt.zero_grad()
+        ref_loss.backward()
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * float(ref_loss.detach()), step
+        if step % 8 == 0:
+            _, exact = oracle_gradients({k: v.detach() for k, v in ref.items()}, lambda p: loss_of(p, lambda t: t.double()),
+                                        torch.float64)
+            noise_floor = max(rel_err(ref[k].grad, exact[k]) for k in ref)
+            for k, p in model.named_parameters():
+                e = rel_err(p.grad.cpu(), ref[k].grad)
+                assert e <= 5e-6 + 8 * noise_floor, (step, k, e, noise_floor)
+        ref_opt.step()
