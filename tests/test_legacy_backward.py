@@ -228,7 +228,7 @@ def test_forty_training_steps_on_the_checkpoints_scene_track_the_oracle(graph):
         assert run._graph is not None and run._graph_rays == batch
     gl, cl, cl64 = (torch.tensor(losses[k], dtype=torch.float64) for k in ("hip", torch.float32, torch.float64))
     assert cl[-10:].mean() < 0.8 * cl[:5].mean()         # it does train
-    assert ((gl[:3] - cl[:3]).abs() <= 1e-5 * cl[:3]).all()              # identical before rounding drift sets in
+    assert abs(gl[0] - cl[0]) <= 1e-6 * cl[0]            # the same loss before the first update
     drift = torch.cummax((cl - cl64).abs(), dim=0).values               # what rounding alone does to this trajectory
     assert ((gl - cl).abs() <= 2e-3 * cl + 8 * drift).all(), ((gl - cl).abs() / (2e-3 * cl + 8 * drift)).max()
     run.iteration = steps
