@@ -61,15 +61,16 @@ def test_parameter_order_is_the_kernels_tensor_order():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("weights,n_rays,num_samples", [("random", 5, 9), ("random", 64, 33), ("random", 130, 64),
-                                                        ("checkpoint", 48, 40), ("random", 3, 100)])
+                                                        ("checkpoint", 48, 40), ("random", 3, 100),
+                                                        ("checkpoint", 48, 64), ("checkpoint", 31, 17), ("init", 64, 48)])
 def test_all_44_gradients_vs_oracle_autograd(weights, n_rays, num_samples):
     dev = torch.device("cuda:0")
     if weights == "checkpoint":
         params, g = checkpoint()
-        o, d = g["rays_o"], g["rays_d"]                           # rays through the trained Lego scene
+        o, d = g["rays_o"][:n_rays], g["rays_d"][:n_rays]         # rays through the trained Lego scene
         near, far = 2.0, 6.0
     else:
-        params = random_params(n_rays)
+        params = random_params(n_rays) if weights == "random" else L.init_params(seed=n_rays)
         gen = torch.Generator().manual_seed(100 + n_rays)
         o, d = torch.randn(n_rays, 3, generator=gen), torch.randn(n_rays, 3, generator=gen)
         near, far = 0.5, 5.0
@@ -100,6 +101,11 @@ def test_all_44_gradients_vs_oracle_autograd(weights, n_rays, num_samples):
         e = rel_err(p.grad.cpu(), ref[k])
         worst = max(worst, e)
         assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+    # (the x2 random networks have samples whose layers are nearly dead — 1/std up to 316 — and a single gate at
+    #  rounding then moves a gradient by percents, in the oracle's fp32-vs-fp64 comparison as in ours; the trained
+    #  checkpoint and the plain initialisation are well conditioned, and there the bound above is tight)
+    if weights != "random":
+        assert worst <= 1e-3, worst
     print(f"[{weights} {n_rays}x{num_samples}] worst relative gradient error {worst:.2e} (oracle fp32 vs fp64: {noise_floor:.2e})")
 
 
