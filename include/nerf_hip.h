@@ -33,11 +33,14 @@ extern "C" {
 #define NERF_HIP_EUNSUPPORTED (-2) /* network shape other than the compiled-in one     */
 #define NERF_HIP_EHIP (-3)     /* a HIP runtime call failed; see nerf_hip_last_error() */
 
-/* Network shape compiled into the kernels: the constructor defaults of
- * nerf/model.py:471-475 (hidden 256, encoding_size 32 -> 96 inputs, 1+3+50 outputs). */
+/* Network shape: hidden_size 256 and encoding_size 32 -> 96 inputs are compiled into the kernels (the
+ * constructor defaults of nerf/model.py:471-475); the number of outputs of the last Linear,
+ * 1 density + 3 color + segmentation_outputs (nerf/model.py:541-542, :591-592), is a run-time argument
+ * `num_outputs` in [4, 64] — the class count is a property of the dataset.  54 for the defaults. */
 #define NERF_HIP_HIDDEN 256
 #define NERF_HIP_ENC_INPUTS 96
-#define NERF_HIP_OUTPUTS 54
+#define NERF_HIP_DEFAULT_OUTPUTS 54
+#define NERF_HIP_MAX_OUTPUTS 64
 #define NERF_HIP_NUM_PARAM_TENSORS 22
 
 #define NERF_HIP_PRECISION_FP32 0
@@ -63,10 +66,10 @@ size_t nerf_hip_packed_bytes(void);
  * MFMA-fragment / LDS-image order the kernels stream.  `params` is a HOST array of 22 DEVICE
  * pointers in state_dict order:
  *   prediction_heads.{0.weight[256,96], 0.bias, 1.weight, 1.bias, 3.weight[256,256], 3.bias,
- *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[54,256], 15.bias[54]}
+ *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[num_outputs,256], 15.bias[num_outputs]}
  * Must be called again whenever the parameters change (once per optimiser step).
  */
-int nerf_hip_pack_weights(const float* const* params, float* packed, void* stream);
+int nerf_hip_pack_weights(const float* const* params, int32_t num_outputs, float* packed, void* stream);
 
 /* Where rays come from and what is written; replaces the bodies of
  * NeRF.render_rays (nerf/model.py:596-668) and NeRF.render_image (:670-770). */
@@ -100,13 +103,13 @@ typedef struct NerfHipRenderArgs {
     const float* packed;        /* image written by nerf_hip_pack_weights                  */
     /* --- outputs */
     float* rgb;                 /* [n_rays,3]  sum_s w_s * sigmoid(color_s)   (model.py:660)*/
-    float* seg;                 /* [n_rays,50] log-probabilities (model.py:661-663) or NULL*/
+    float* seg;                 /* [n_rays,num_outputs-4] log-probabilities (model.py:661-663) or NULL */
     /* optional per-sample outputs of NeRF.forward (model.py:553-594), any may be NULL      */
     float* out_mean;            /* [n_rays,S-1,3]  Gaussian means (model.py:587)           */
     float* out_cov;             /* [n_rays,S-1,3]  diagonal covariances (debug / parity)   */
     float* out_t;               /* [n_rays,S] the fenceposts used (sample_along_rays,
                                    model.py:369-435; with rng_mode bit0: the in-kernel draws) */
-    float* out_raw;             /* [n_rays,S-1,54] density | color | segmentation logits   */
+    float* out_raw;             /* [n_rays,S-1,num_outputs] density | color | segmentation logits */
     float* out_weights;         /* [n_rays,S-1] compositing weights (model.py:438-469)     */
     /* training: non-NULL makes the forward also save what the backward needs (activations,
      * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats      */
@@ -119,6 +122,10 @@ typedef struct NerfHipRenderArgs {
      * F16X3 = every fp32 operand split into an f16 pair, three f16 MFMAs per product with fp32
      *         accumulation (~2^-22 relative per product; same 1e-4 RGB parity bar)            */
     int32_t precision;
+    /* rows of the last Linear = 1 density + 3 color + segmentation classes, 4 .. 64 (54 for the
+     * reference's defaults; must be what nerf_hip_pack_weights was given).  With 4 (no classes) `seg`
+     * must be NULL.  The legacy-network entry points ignore it. */
+    int32_t num_outputs;
 } NerfHipRenderArgs;
 
 /* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional
@@ -128,9 +135,9 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream);
 /* Bytes of `train_workspace` for a batch of n_rays rays at num_samples fenceposts. */
 size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples);
 
-/* Number of fp32 elements of the flat gradient vector (304,438): the 22 parameter tensors in
- * state_dict order, each in its PyTorch layout. */
-size_t nerf_hip_grad_elements(void);
+/* Number of fp32 elements of the flat gradient vector: the 22 parameter tensors in state_dict order,
+ * each in its PyTorch layout (304,438 for num_outputs = 54; 0 if num_outputs is out of range). */
+size_t nerf_hip_grad_elements(int32_t num_outputs);
 
 /* Backward of nerf_hip_render_forward w.r.t. the parameters (replaces PyTorch autograd through
  * NeRF.render_rays, driven by loss.backward() at train_conditional_nerf.py:133).  `fwd` must be
@@ -139,8 +146,8 @@ size_t nerf_hip_grad_elements(void);
 typedef struct NerfHipBackwardArgs {
     NerfHipRenderArgs fwd;
     const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
-    const float* d_seg;         /* [n_rays,50] dL/d seg or NULL (RGB-only loss)           */
-    float* grad;                /* [nerf_hip_grad_elements()] written (not accumulated)    */
+    const float* d_seg;         /* [n_rays,num_outputs-4] dL/d seg or NULL (RGB-only loss) */
+    float* grad;                /* [nerf_hip_grad_elements(num_outputs)] written (not accumulated) */
     float* scratch;             /* nerf_hip_backward_scratch_bytes() bytes                 */
 } NerfHipBackwardArgs;
 

@@ -56,14 +56,15 @@ class RenderRaysFunction(torch.autograd.Function):
         d_rgb = d_rgb.contiguous()
         # d_seg is None when the segmentation output did not reach the loss (no device sync to find
         # out): the kernels then skip the 50-class branch of the compositing backward
-        d_seg = d_seg.contiguous() if d_seg is not None else None
+        d_seg = d_seg.contiguous() if d_seg is not None and model.segmentation_outputs > 0 else None
 
         args = _lib.BackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, u=u,
                          t_values=t_values, noise=noise, density_noise_std=std, rng_mode=rng_mode, rng_state=rng_state,
-                         packed=ctx.packed, rgb=rgb, seg=seg, train_workspace=ctx.workspace,
+                         packed=ctx.packed, rgb=rgb, seg=seg if model.segmentation_outputs > 0 else None,
+                         train_workspace=ctx.workspace,
                          precision=ctx.precision)
-        grad = torch.empty(lib.nerf_hip_grad_elements(), dtype=torch.float32, device=device)
+        grad = torch.empty(lib.nerf_hip_grad_elements(model.num_outputs), dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
         args.d_rgb, args.d_seg = _lib.ptr(d_rgb), _lib.ptr(d_seg)
         args.grad, args.scratch = _lib.ptr(grad), _lib.ptr(scratch)

@@ -310,17 +310,15 @@ __device__ __forceinline__ int layer0_kernel_column(int feature) {
 }
 
 constexpr int kReduceThreads = 256;
-constexpr int kReduceDirectBlocks = (kGradElements + kReduceThreads - 1) / kReduceThreads;
 constexpr int kGbElements = 5 * 2 * kHidden;                       // gamma / beta gradients
 constexpr int kReduceGbBlocks = kGbElements / 4;                   // one wave per element
 
-__device__ __forceinline__ void locate(int e, int& tensor, int& idx) {
+__device__ __forceinline__ void locate(int e, int n_out, int& tensor, int& idx) {
     tensor = 0;
     int off = 0;
     for (;;) {
         const int L = tensor / 4, which = tensor % 4;
-        const int n = which == 0 ? (L == 0 ? kHidden * kEncIn : (L == 5 ? kOut * kHidden : kHidden * kHidden))
-                                 : (L == 5 ? kOut : kHidden);
+        const int n = tensor_elements(tensor, n_out);
         if (e < off + n) break;
         off += n;
         ++tensor;
@@ -333,22 +331,23 @@ __device__ __forceinline__ void locate(int e, int& tensor, int& idx) {
 // per data-gradient WORKGROUP (up to 1,024 terms): one wave per element, lane l sums partials
 // l, l + 64, ... and the lanes combine in a fixed butterfly — still one fixed association.
 __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
-    if ((int)blockIdx.x >= kReduceDirectBlocks) {
+    const int direct_blocks = (grad_elements(ba.a.num_outputs) + kReduceThreads - 1) / kReduceThreads;
+    if ((int)blockIdx.x >= direct_blocks) {
         const int lane = threadIdx.x & 63;
-        const int ge = ((int)blockIdx.x - kReduceDirectBlocks) * 4 + (threadIdx.x >> 6);   // [layer][gamma|beta][256]
+        const int ge = ((int)blockIdx.x - direct_blocks) * 4 + (threadIdx.x >> 6);   // [layer][gamma|beta][256]
         const int L = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
         const float* p = ba.gb_partial + ge;
         float sum = 0.f;
         for (int q = lane; q < ba.data_grid; q += 64) sum += p[(int64_t)q * kGbFloats];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-        if (lane == 0) ba.grad[grad_offset(4 * L + 2 + which) + idx] = sum;
+        if (lane == 0) ba.grad[grad_offset(4 * L + 2 + which, ba.a.num_outputs) + idx] = sum;
         return;
     }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kGradElements) return;
+    if (e >= grad_elements(ba.a.num_outputs)) return;
     int tensor, idx;
-    locate(e, tensor, idx);
+    locate(e, ba.a.num_outputs, tensor, idx);
     const int L = tensor / 4, which = tensor % 4;
     if (which >= 2) return;                       // gamma / beta: the blocks behind
     int so;
@@ -383,8 +382,10 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     const NerfHipRenderArgs& a = args->fwd;
     if (args->grad == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad is null");
+    if (a.num_outputs < kMinOutputs || a.num_outputs > kOutPad)
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_backward: num_outputs must be 4 .. 64");
     if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
-        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)kGradElements * sizeof(float),
+        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)grad_elements(a.num_outputs) * sizeof(float),
                                                      (hipStream_t)stream), "render_backward memset");
     if (args->scratch == nullptr || args->d_rgb == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: scratch / d_rgb is null");
@@ -449,7 +450,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
     else
         hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
-    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks), dim3(kReduceThreads),
+    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(a.num_outputs) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
                        0, st, ba);
     return nerf_common::check_hip(hipGetLastError(), "render_backward launch");
 }

@@ -172,9 +172,9 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = 16 * T + 4 * g + r;
-                            if (ray_ok && n >= 4 && n < kOut) {
-                                gseg[4 * T + r] = ba.d_seg[local * kSegClasses + (n - 4)];
-                                oseg[4 * T + r] = a.seg[local * kSegClasses + (n - 4)];
+                            if (ray_ok && n >= 4 && n < a.num_outputs) {
+                                gseg[4 * T + r] = ba.d_seg[local * (a.num_outputs - 4) + (n - 4)];
+                                oseg[4 * T + r] = a.seg[local * (a.num_outputs - 4) + (n - 4)];
                             }
                         }
                     m = -__builtin_inff();
@@ -182,21 +182,21 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
+                            if (is_seg_slot(T, g, r, a.num_outputs)) m = __builtin_fmaxf(m, out[T][r]);
                     m = group_max(m);
                     float z = 0.f;
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) z += expf(out[T][r] - m);
+                            if (is_seg_slot(T, g, r, a.num_outputs)) z += expf(out[T][r] - m);
                     logz = logf(group_sum(z));
                     lw = logf(w + 1e-10f);
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r)) {
+                            if (is_seg_slot(T, g, r, a.num_outputs)) {
                                 const float rho = expf(lw + ((out[T][r] - m) - logz) - oseg[4 * T + r]);
                                 srho = __builtin_fmaf(gseg[4 * T + r], rho, srho);
                             }
@@ -215,7 +215,7 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                     for (int r = 0; r < 4; ++r) {
                         const int n = 16 * T + 4 * g + r;
                         float v = 0.f;
-                        if (n >= 4 && n < kOut && with_seg) {
+                        if (n >= 4 && n < a.num_outputs && with_seg) {
                             const float lp = (out[T][r] - m) - logz;
                             const float rho = expf(lw + lp - oseg[4 * T + r]);
                             v = gseg[4 * T + r] * rho - expf(lp) * srho;

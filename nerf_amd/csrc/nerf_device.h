@@ -471,10 +471,10 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // Output slot n = 16 T + 4 g + reg of the padded last layer: 0 density, 1..3 color,
-// 4..53 segmentation classes, 54..63 padding (nerf/model.py:591-592).
-__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg) {
+// 4..n_out-1 segmentation classes (4..53 for the reference's 50), the rest padding (nerf/model.py:591-592).
+__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg, int n_out) {
     const int n = 16 * T + 4 * g + reg;
-    return n >= 4 && n < kOut;
+    return n >= 4 && n < n_out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,14 +675,14 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r)) m = __builtin_fmaxf(m, out[T][r]);
+                if (is_seg_slot(T, g, r, a.num_outputs)) m = __builtin_fmaxf(m, out[T][r]);
         m = group_max(m);
         float z = 0.f;
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r)) z += exp_fast(out[T][r] - m);
+                if (is_seg_slot(T, g, r, a.num_outputs)) z += exp_fast(out[T][r] - m);
         z = group_sum(z);
         const float logz = logf(z);
         const float lw = logf(w + 1e-10f);
@@ -724,7 +724,7 @@ __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t lo
         const int j = lane & 15, g = lane >> 4;
         const float mine = acc.seg_m + logf(acc.seg_s);
         const int n = 16 * (j >> 2) + 4 * g + (j & 3);
-        if (ray_ok && n >= 4 && n < kOut) a.seg[local * kSegClasses + (n - 4)] = mine;
+        if (ray_ok && n >= 4 && n < a.num_outputs) a.seg[local * (a.num_outputs - 4) + (n - 4)] = mine;
     }
 }
 

@@ -26,9 +26,9 @@ namespace nerf_layout {
 
 constexpr int kHidden = 256;
 constexpr int kEncIn = 96;
-constexpr int kOut = 54;
-constexpr int kOutPad = 64;
-constexpr int kSegClasses = 50;
+constexpr int kOutPad = 64;      // the last layer's outputs padded to four 16-row tiles; the number in use
+                                 // (1 density + 3 color + segmentation classes, <= 64) is a launch argument
+constexpr int kMinOutputs = 4;   // density + color, no segmentation classes
 
 constexpr int kStageBytes = 16384;
 constexpr int kStageFloats = kStageBytes / 4;
@@ -75,20 +75,20 @@ constexpr int kHSmallOffset = kHBlobOffset + kBlobFloats;
 constexpr int kBwdHBlobOffset = kHSmallOffset + kSmallFloats;
 constexpr int kPackedFloats = kBwdHBlobOffset + kBwdBlobFloats;
 
-// flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts
-constexpr int kGradElements = kHidden * kEncIn + kHidden + 2 * kHidden
-                              + 4 * (kHidden * kHidden + kHidden + 2 * kHidden)
-                              + kOut * kHidden + kOut;                  // 304,438
-__host__ __device__ inline int grad_offset(int tensor) {
+// flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts; n_out = rows of the last Linear
+// (304,438 elements for the reference's default 1 + 3 + 50 outputs)
+__host__ __device__ inline int tensor_elements(int tensor, int n_out) {
     // tensor index in state_dict order: 4 L + {0 W, 1 b, 2 gamma, 3 beta} for L < 5; 20 W5, 21 b5
+    const int L = tensor / 4, which = tensor % 4;
+    if (which == 0) return L == 0 ? kHidden * kEncIn : (L == 5 ? n_out * kHidden : kHidden * kHidden);
+    return L == 5 ? n_out : kHidden;
+}
+__host__ __device__ inline int grad_offset(int tensor, int n_out) {
     int off = 0;
-    for (int i = 0; i < tensor; ++i) {
-        const int L = i / 4, which = i % 4;
-        if (which == 0) off += (L == 0 ? kHidden * kEncIn : (L == 5 ? kOut * kHidden : kHidden * kHidden));
-        else off += (L == 5 ? kOut : kHidden);
-    }
+    for (int i = 0; i < tensor; ++i) off += tensor_elements(i, n_out);
     return off;
 }
+__host__ __device__ inline int grad_elements(int n_out) { return grad_offset(22, n_out); }
 
 // Input-feature permutation of layer 0: lane group g computes, for the Gaussian of its sample,
 // the 12 (scale, coord) pairs with scale index 4 g .. 4 g + 3; local slot q = 4 t + r:

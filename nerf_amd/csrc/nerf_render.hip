@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = 16 * T + 4 * g + r;
-                            if (n < kOut) a.out_raw[smp * kOut + n] = out[T][r];
+                            if (n < a.num_outputs) a.out_raw[smp * a.num_outputs + n] = out[T][r];
                         }
                 }
                 if (g == 0) {
@@ -673,6 +673,7 @@ __global__ __launch_bounds__(256) void nerf_composite_fwd_kernel(const KernelArg
 struct PackArgs {
     const float* p[NERF_HIP_NUM_PARAM_TENSORS];
     float* packed;
+    int32_t n_out;              // rows of the last Linear (1 + 3 + segmentation classes); padded to 64 with zeros
 };
 
 __global__ void nerf_pack_kernel(const PackArgs pa) {
@@ -697,7 +698,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int s = stage - (kStagesL0 + 4 * kStagesHidden);
             const int t = 4 * s + quad / 4, T = quad % 4;
             const int out = 16 * T + row;
-            if (out < kOut) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
+            if (out < pa.n_out) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
         }
     } else if (e >= kBwdHBlobOffset) {
         // transposed split-precision image (nerf_layout.h): two f16 of one slab per float slot
@@ -717,7 +718,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             if (stage < kStagesL5) {
                 const int half = stage / 2, m = stage % 2;
                 const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
-                if (out < kOut) w = pa.p[20][out * kHidden + 16 * (8 * half + pair) + row];
+                if (out < pa.n_out) w = pa.p[20][out * kHidden + 16 * (8 * half + pair) + row];
             } else {
                 const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
                 const int s = (stage - kStagesL5) % kStagesHidden;
@@ -746,7 +747,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int q = i - 5 * kSmallPerLayer;
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
             const int n = 16 * T + 4 * g + reg;
-            if (n < kOut) v = pa.p[21][n] * sb;
+            if (n < pa.n_out) v = pa.p[21][n] * sb;
         }
     } else if (e >= kHBlobOffset) {
         // split-precision image (nerf_layout.h): this float slot carries two f16 of one slab
@@ -778,7 +779,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
                 const int s = stage - (kStagesL0 + 4 * kStagesHidden);
                 const int m = 2 * s + (pair >> 2), T = pair & 3;
                 const int out = 16 * T + row;
-                if (out < kOut) w = pa.p[20][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
+                if (out < pa.n_out) w = pa.p[20][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
             }
             w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
             const _Float16 hi = (_Float16)w;              // round to nearest
@@ -796,7 +797,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         const int i = lane & 15, g = lane >> 4;
         if (stage < kStagesL5) {
             const int out = 16 * stage + 4 * g + r;
-            if (out < kOut) v = pa.p[20][out * kHidden + 16 * tin + i];
+            if (out < pa.n_out) v = pa.p[20][out * kHidden + 16 * tin + i];
         } else {
             const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
             const int tout = (stage - kStagesL5) % kStagesHidden;
@@ -815,7 +816,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int q = i - 5 * kSmallPerLayer;                   // last bias [g][T(4)][reg]
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
             const int n = 16 * T + 4 * g + reg;
-            if (n < kOut) v = pa.p[21][n];
+            if (n < pa.n_out) v = pa.p[21][n];
         }
     }
     pa.packed[e] = v;
@@ -842,12 +843,18 @@ size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
     return (size_t)make_train_layout(n_rays, chunks).total * sizeof(float);
 }
 
-size_t nerf_hip_grad_elements(void) { return (size_t)kGradElements; }
+size_t nerf_hip_grad_elements(int32_t num_outputs) {
+    if (num_outputs < kMinOutputs || num_outputs > kOutPad) return 0;
+    return (size_t)grad_elements(num_outputs);
+}
 
-int nerf_hip_pack_weights(const float* const* params, float* packed, void* stream) {
+int nerf_hip_pack_weights(const float* const* params, int32_t num_outputs, float* packed, void* stream) {
     if (params == nullptr || packed == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "pack_weights: null pointer");
+    if (num_outputs < kMinOutputs || num_outputs > kOutPad)
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "pack_weights: num_outputs must be 4 .. 64 (1 density + 3 color + segmentation classes)");
     PackArgs pa;
+    pa.n_out = num_outputs;
     for (int i = 0; i < NERF_HIP_NUM_PARAM_TENSORS; ++i) {
         if (params[i] == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "pack_weights: null tensor");
         pa.p[i] = params[i];
@@ -866,6 +873,10 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: n_rays / num_samples out of range");
     if (a.packed == nullptr || a.rgb == nullptr || (a.t_table == nullptr && a.t_values == nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: packed / rgb / t_table is null");
+    if (a.num_outputs < kMinOutputs || a.num_outputs > kOutPad)
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_forward: num_outputs must be 4 .. 64 (1 density + 3 color + segmentation classes)");
+    if (a.num_outputs == kMinOutputs && a.seg != nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: seg given but the network has no segmentation classes");
     const bool arrays = a.rays_o != nullptr && a.rays_d != nullptr;
     const bool cameras = a.camera_o != nullptr && a.camera_r != nullptr && a.image_h > 0 &&
                          a.image_w > 0 && a.focal_length != 0.f;

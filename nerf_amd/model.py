@@ -229,12 +229,20 @@ class NeRF(nn.Module):
 
     # ---- plumbing to the C ABI -------------------------------------------------------------------
 
+    @property
+    def num_outputs(self):
+        """Rows of the last Linear: density | color | segmentation (nerf/model.py:541-542)."""
+        return 1 + self.color_outputs + self.segmentation_outputs
+
     def _check_shape(self):
-        if (self.hidden_size, self.encoding_size,
-                1 + self.color_outputs + self.segmentation_outputs, self.color_outputs) != (256, 32, 54, 3):
+        """The kernels take the number of segmentation classes at run time (any count with
+        1 + 3 + classes <= 64 fits the padded 64-row output tile); hidden_size, encoding_size and the three
+        color channels are compiled in (the only shapes the reference's scripts use)."""
+        if (self.hidden_size, self.encoding_size, self.color_outputs) != (256, 32, 3) or \
+                not 0 <= self.segmentation_outputs <= 60:
             raise NotImplementedError(
-                "libnerf_hip is compiled for the reference's default network "
-                "(hidden_size=256, encoding_size=32, 3 color + 50 segmentation outputs)")
+                "libnerf_hip is compiled for hidden_size=256, encoding_size=32, color_outputs=3 and takes "
+                "0 <= segmentation_outputs <= 60 (the reference's defaults: 256 / 32 / 3 / 50)")
 
     def _param_list(self):
         heads = self.prediction_heads
@@ -262,7 +270,7 @@ class NeRF(nn.Module):
             packed = torch.empty(lib.nerf_hip_packed_bytes() // 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.nerf_hip_pack_weights(ptrs, _lib.ptr(packed), ctypes.c_void_p(stream)),
+            _lib.check(lib.nerf_hip_pack_weights(ptrs, self.num_outputs, _lib.ptr(packed), ctypes.c_void_p(stream)),
                        "nerf_hip_pack_weights")
         if not fresh:
             self._packed = packed
@@ -345,6 +353,7 @@ class NeRF(nn.Module):
         args.out_mean, args.out_cov, args.out_t = _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(out_t)
         args.out_raw, args.out_weights = _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
+        args.num_outputs = self.num_outputs
         if precision is not None:
             args.precision = precision
             return
@@ -373,10 +382,12 @@ class NeRF(nn.Module):
             rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
         if seg is None and want_seg:
             seg = torch.empty(n_rays, self.segmentation_outputs, dtype=torch.float32, device=device)
+        if self.segmentation_outputs == 0:
+            seg_given, seg = seg, None                  # no classes: nothing for the kernel to write
         mean = raw = weights = None
         if per_sample:
             mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
-            raw = torch.empty(n_rays, P, 54, dtype=torch.float32, device=device)
+            raw = torch.empty(n_rays, P, self.num_outputs, dtype=torch.float32, device=device)
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         elif want_weights:
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
@@ -392,6 +403,8 @@ class NeRF(nn.Module):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nerf_hip_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
                        "nerf_hip_render_forward")
+        if self.segmentation_outputs == 0:
+            seg = seg_given                              # the caller's empty [n, 0] tensor (or None)
         return rgb, seg, mean, raw, weights
 
     def _draws(self, n_rays, num_samples, device, randomly_sample, density_noise_std):

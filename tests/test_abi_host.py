@@ -35,7 +35,9 @@ def test_library_exports_every_declared_symbol(handle):
     assert handle.nerf_hip_version() == _lib.ABI_VERSION == 4
     # packed image = {74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB} x {fp32, f16 pairs}
     assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4 + 68 * 16384)
-    assert handle.nerf_hip_grad_elements() == 304438
+    assert handle.nerf_hip_grad_elements(54) == 304438        # the reference's 1 + 3 + 50 outputs
+    assert handle.nerf_hip_grad_elements(4) == 304438 - 50 * 257 and handle.nerf_hip_grad_elements(64) == 304438 + 10 * 257
+    assert handle.nerf_hip_grad_elements(3) == 0 and handle.nerf_hip_grad_elements(65) == 0
     assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 2793 * 4
     assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
 
@@ -72,11 +74,16 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     args = _lib.RenderArgs()
     args.n_rays, args.num_samples = 8, 4
     args.rays_o = args.rays_d = args.packed = args.rgb = args.t_table = dummy
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -2      # num_outputs unset (0): unsupported shape
+    assert b"num_outputs" in handle.nerf_hip_last_error()
+    args.num_outputs = 65
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -2
+    args.num_outputs = 54
     args.precision = 7
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     assert b"precision" in handle.nerf_hip_last_error()
     assert handle.nerf_hip_build_flags() == b""          # the product build carries no experiment macro
-    assert handle.nerf_hip_pack_weights(None, None, None) == -1
+    assert handle.nerf_hip_pack_weights(None, 54, None, None) == -1
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()
     assert handle.nerf_hip_render_backward(ctypes.byref(bargs), None) == -1

@@ -31,6 +31,7 @@ class ReferenceShapedModule(nn.Module):
     def __init__(self, focal_length=112.0):
         super().__init__()
         self.focal_length = focal_length
+        self.color_outputs, self.segmentation_outputs = 3, 50
         self.register_buffer("rays_min", torch.zeros(1, 1, 3))
         self.register_buffer("rays_max", torch.zeros(1, 1, 3))
         layers = [nn.Linear(96, 256), nn.LayerNorm(256), nn.ReLU()]

@@ -1,0 +1,116 @@
+"""Run-time output width: ``NeRF(segmentation_outputs=...)`` is a constructor keyword of the reference
+(nerf/model.py:471-475; the last Linear has 1 + color_outputs + segmentation_outputs rows, :541-542, split
+[1, 3, seg] at :591-592) and the class count is a property of the dataset, so the kernels take it per launch:
+any count with 1 + 3 + classes <= 64 fits the padded 64-row output tile.  Forward (stage vectors, rendered RGB
+and segmentation log-probabilities) and backward (all 22 gradients) against the oracle at 0, 7 and 60 classes;
+tolerances as for the default network (tests/test_gpu_forward.py, tests/test_gpu_backward.py)."""
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(classes, seed, scale=2.0):
+    from nerf_amd import NeRF
+    cfg = dict(O.default_config(), segmentation_outputs=classes)
+    params = O.init_params(seed=seed, cfg=cfg)
+    for slot in O.LINEAR_IDS:
+        params[f"prediction_heads.{slot}.weight"] = params[f"prediction_heads.{slot}.weight"] * scale
+    torch.manual_seed(seed + 1)
+    for k in list(params):                              # non-trivial LayerNorm affine and biases
+        if k.startswith("prediction") and params[k].dim() == 1:
+            params[k] = params[k] + 0.2 * torch.randn_like(params[k])
+    model = NeRF(segmentation_outputs=classes)
+    model.load_state_dict(params)
+    return cfg, params, model.to(torch.device("cuda:0"))
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("classes", [0, 7, 60])
+def test_forward_vs_oracle(classes, precision):
+    dev = torch.device("cuda:0")
+    cfg, params, model = setup(classes, seed=classes)
+    model.precision = precision
+    assert model.num_outputs == 4 + classes
+    n, S = 77, 40
+    g = torch.Generator().manual_seed(3)
+    cam_o = torch.tensor([[0.0, -3.0, 2.6]])
+    cam_r = O.look_at_pose([0.0, -3.0, 2.6])
+    rays_o, rays_d = O.image_rays(cam_o, cam_r, 11, 7, 12.3)
+    u = torch.rand(n, S, generator=g)
+    with torch.no_grad():
+        ref_rgb, ref_seg, st = O.render_rays(params, cfg, rays_o, rays_d, S, u=u, return_stages=True)
+        rgb, seg = model.render_rays(rays_o.to(dev), rays_d.to(dev), S, randomly_sample=True, u=u.to(dev))
+        mean, density, color, seg_logits = model.forward(rays_o.to(dev), rays_d.to(dev), st["t"].to(dev))
+        img, img_seg = model.render_image(cam_o.to(dev), cam_r.to(dev), 11, 7, 12.3, S)
+        det_rgb, det_seg = O.render_rays(params, cfg, rays_o, rays_d, S)
+    assert rgb.shape == (n, 1, 3) and seg.shape == (n, 1, classes) and seg_logits.shape == (n, S - 1, classes)
+    assert img.shape == (1, 11, 7, 3) and img_seg.shape == (1, 11, 7, classes)
+    assert (density.cpu() - st["density"]).abs().max() <= 2e-5 * max(1.0, float(st["density"].abs().max()))
+    assert (color.cpu() - st["color"]).abs().max() <= 2e-5 * max(1.0, float(st["color"].abs().max()))
+    ok = st["density"][:, -1, 0].abs() > 1e-5                       # the 1e10-wide last interval
+    assert (rgb[:, 0].cpu() - ref_rgb)[ok].abs().max() <= 1e-5
+    if classes:
+        assert (seg_logits.cpu() - st["seg"]).abs().max() <= 2e-5 * max(1.0, float(st["seg"].abs().max()))
+        assert (seg[:, 0].cpu() - ref_seg)[ok].abs().max() <= 1e-4
+        # log-probabilities: the classes of a ray sum (in probability) to the ray's total weight, at most 1
+        assert float(seg[:, 0].exp().sum(-1).max()) <= 1.0 + 1e-4
+    with torch.no_grad():
+        det = O.render_rays(params, cfg, rays_o, rays_d, S, return_stages=True)[2]["density"][:, -1, 0].abs() > 1e-5
+    assert (img.reshape(-1, 3).cpu() - det_rgb)[det].abs().max() <= 1e-5
+    if classes:
+        assert (img_seg.reshape(-1, classes).cpu() - det_seg)[det].abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("classes", [0, 7, 60])
+def test_gradients_vs_oracle_autograd(classes, train_precision):
+    dev = torch.device("cuda:0")
+    cfg, params, model = setup(classes, seed=10 + classes)
+    model.train_precision = train_precision
+    n, S = 70, 33
+    g = torch.Generator().manual_seed(5)
+    o, d = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    u = torch.rand(n, S, generator=g)
+    noise = torch.randn(n, S - 1, 1, generator=g)
+    w_rgb = torch.randn(n, 3, generator=g)
+    w_seg = torch.randn(n, classes, generator=g) * 0.05
+
+    def loss_of(p, cast):
+        rgb, seg = O.render_rays(p, cfg, cast(o), cast(d), S, u=cast(u), noise=cast(noise), density_noise_std=0.5)
+        return (rgb * cast(w_rgb)).sum() + (seg * cast(w_seg)).sum()
+
+    def grads(dtype):
+        p = {k: v.to(dtype).clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+        loss = loss_of(p, lambda t: t.to(dtype))
+        loss.backward()
+        return float(loss.detach()), {k: v.grad.float() for k, v in p.items() if v.grad is not None}
+
+    loss_r, ref = grads(torch.float32)
+    _, exact = grads(torch.float64)
+    noise_floor = max(rel_err(ref[k], exact[k]) for k in ref)
+    rgb, seg = model.render_rays(o.to(dev), d.to(dev), S, randomly_sample=True, density_noise_std=0.5,
+                                 u=u.to(dev), noise=noise.to(dev))
+    loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + (seg[:, 0] * w_seg.to(dev)).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_r) <= 1e-4 * max(1.0, abs(loss_r))
+    assert model.last_flat_grad.numel() == 304438 + (classes - 50) * 257
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == ref[k].shape, k
+        e = rel_err(p.grad.cpu(), ref[k])
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+
+
+def test_shapes_the_kernels_do_not_take_are_refused():
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    o = torch.randn(4, 3, device=dev)
+    for kwargs in (dict(segmentation_outputs=61), dict(hidden_size=128), dict(encoding_size=16), dict(color_outputs=4)):
+        with pytest.raises(NotImplementedError):
+            NeRF(**kwargs).to(dev).render_rays(o, o, 8)
