@@ -70,9 +70,9 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     float s1 = 0.f, s2 = 0.f;
-    f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
+    // One tile: ReLU gate, gamma d z into the accumulator, the two LayerNorm moments; v[0..3] = d z (beta
+    // gradient terms), v[4..7] = d z x_hat (gamma gradient terms) of the tile's four registers.
+    auto tile = [&](int T, float (&v)[8]) {
         const f32x4 ga = gam[T], be = bet[T];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -80,19 +80,30 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             float dz;               // (if constexpr: a ?: on kScaled costs the fp32 kernel 60 spilled registers)
             if constexpr (kScaled) dz = z > 0.f ? acc[T][r] * unscale : 0.f;
             else dz = z > 0.f ? acc[T][r] : 0.f;
-            // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
-            const float rb = row_sum(dz);
-            const float rg = row_sum(dz * xh[T][r]);
-            if (j == T) {
-                keep_b[r] = rb;
-                keep_g[r] = rg;
-            }
+            v[r] = dz;
+            v[4 + r] = dz * xh[T][r];
             const float gdz = ga[r] * dz;
             s1 += gdz;
             s2 = __builtin_fmaf(gdz, xh[T][r], s2);
             acc[T][r] = gdz;
         }
+    };
+    // beta / gamma gradients: sums over the 16 samples of a row, lane j keeps tile j — a reduce-scatter
+    // butterfly (nerf_device.h: scatter_level8 / 4 / take) applied as the tiles come: t, t + 8, t + 4, t + 12
+    float kept[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float va[8], vb[8], w0[8], w1[8], x[8];
+        tile(t, va);
+        tile(t + 8, vb);
+        scatter_level8(va, vb, w0);
+        tile(t + 4, va);
+        tile(t + 12, vb);
+        scatter_level8(va, vb, w1);
+        scatter_level4(w0, w1, x);
+        scatter_take(x, t, j, kept);
     }
+    const f32x4 keep_b = {kept[0], kept[1], kept[2], kept[3]}, keep_g = {kept[4], kept[5], kept[6], kept[7]};
     turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
     turn.kg = keep_g;
     turn.kb = keep_b;

@@ -430,6 +430,81 @@ __device__ __forceinline__ float row_suffix_sum(float v) {
     v += dpp<0x108>(0.f, v);
     return v;
 }
+// Reduce-scatter over the 16 lanes of a row, eight quantities at a time: from per-tile values v[T][i]
+// (T = 0..15 tiles, i = 0..7 quantities, one register each) lane j of every row ends with the sums over the
+// row's lanes of v[T = j][i].  Butterfly: distance 8 (lanes 0-7 keep tile t, lanes 8-15 tile t + 8:
+// scatter_level8), distance 4 (banks 0, 2 keep tile t, banks 1, 3 tile t + 4 of their half: scatter_level4),
+// then an all-reduce inside the quad, of which the lane with t = lane-in-quad keeps the result (scatter_take):
+// per value 1 + 0.5 + 0.5 DPP adds and a quarter of a select, against 4 DPP adds + a select for a row_sum() of which one lane in
+// sixteen keeps the result.  The levels can be applied as soon as their two inputs exist, so a caller that
+// walks the tiles in the order t, t + 8, t + 4, t + 12 never holds more than a few tiles' values.
+// (scripts/probes/row_scatter_sum.hip checks the lane semantics on the hardware.)
+// The two halves of a level are bank-masked DPP adds into one register, which the compiler does not
+// generate: inline asm.  Asm gets no hazard wait states from the compiler: `s_nop 1` covers "VALU write ->
+// DPP read of the same VGPR" (2 wait states), and the inputs must not be raw results of MFMAs still in
+// flight (nerf_amd/isa_scan.py rule R1) — callers pass values a visible VALU instruction produced.
+#define NERF_DPP8(ctrl, mask, first)                                                               \
+    "v_add_f32_dpp %0, %" #first ", %" #first " " ctrl " row_mask:0xf bank_mask:" mask "\n\t"
+__device__ __forceinline__ void scatter_level8(const float (&lo)[8], const float (&hi)[8], float (&out)[8]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]),
+          "=&v"(out[7])
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
+          "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
+}
+// banks 0, 2 take `lo` from the lane 4 above (row_shl), banks 1, 3 `hi` from the lane 4 below (row_shr)
+__device__ __forceinline__ void scatter_level4(const float (&lo)[8], const float (&hi)[8], float (&out)[8]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %17, %17 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %19, %19 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %21, %21 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %23, %23 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]),
+          "=&v"(out[7])
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
+          "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
+}
+#undef NERF_DPP8
+// x[i]: the level-4 results of tile group t (tiles t, t + 4, t + 8, t + 12) -> all-reduce inside the quad; the
+// lane whose position in its quad is t keeps them: after t = 0..3, kept[i] = the row's sum of tile
+// 4 bank + (lane & 3) = tile (lane & 15)
+__device__ __forceinline__ void scatter_take(float (&x)[8], int t, int lane, float (&kept)[8]) {
+    const bool mine = (lane & 3) == t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] += dpp<kQuadXor1>(0.f, x[i]);
+        x[i] += dpp<kQuadXor2>(0.f, x[i]);
+        kept[i] = mine ? x[i] : kept[i];
+    }
+}
 __device__ __forceinline__ float row_shift_up(float fill, float v) { return dpp<0x111>(fill, v); }    // from j-1
 __device__ __forceinline__ float row_shift_down(float fill, float v) { return dpp<0x101>(fill, v); }  // from j+1
 

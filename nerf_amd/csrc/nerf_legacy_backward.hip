@@ -97,26 +97,39 @@ __device__ __forceinline__ void relu_layer_norm_bwd(const float* gamma_l, int g,
                                                     float shift, float* dy_row, float* gb_l, GammaBetaTurn& turn) {
     const f32x4* gam = (const f32x4*)(gamma_l + g * 64);
     float s1 = 0.f, s2 = 0.f;
-    f32x4 keep_b = {0.f, 0.f, 0.f, 0.f}, keep_g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int T = 0; T < 16; ++T) {
+    // one tile: gamma d x' into the accumulator, the two LayerNorm moments; v[0..3] = d x' (beta gradient
+    // terms), v[4..7] = d x' a_hat (gamma gradient terms)
+    auto tile = [&](int T, float (&v)[8]) {
         const f32x4 ga = gam[T];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float dz = acc[T][r];
-            // beta / gamma gradients: sum over the 16 samples of the row; lane j == T keeps tile T
-            const float rb = row_sum(dz);
-            const float rg = row_sum(dz * xh[T][r]);
-            if (j == T) {
-                keep_b[r] = rb;
-                keep_g[r] = rg;
-            }
+            // (the median of three copies: the value the inline-asm butterfly reads is then a VALU result, not
+            //  the raw accumulator of an MFMA that may still be in flight — nerf_amd/isa_scan.py rule R1)
+            v[r] = __builtin_amdgcn_fmed3f(dz, dz, dz);
+            v[4 + r] = dz * xh[T][r];
             const float gdz = ga[r] * dz;
             s1 += gdz;
             s2 = __builtin_fmaf(gdz, xh[T][r], s2);
             acc[T][r] = gdz;
         }
+    };
+    // sums over the 16 samples of a row, lane j keeps tile j: reduce-scatter butterfly as the tiles come
+    // (nerf_device.h: scatter_level8 / 4 / take)
+    float kept[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float va[8], vb[8], w0[8], w1[8], x[8];
+        tile(t, va);
+        tile(t + 8, vb);
+        scatter_level8(va, vb, w0);
+        tile(t + 4, va);
+        tile(t + 12, vb);
+        scatter_level8(va, vb, w1);
+        scatter_level4(w0, w1, x);
+        scatter_take(x, t, j, kept);
     }
+    const f32x4 keep_b = {kept[0], kept[1], kept[2], kept[3]}, keep_g = {kept[4], kept[5], kept[6], kept[7]};
     turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
     turn.kg = keep_g;
     turn.kb = keep_b;
