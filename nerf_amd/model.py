@@ -579,12 +579,33 @@ class NeRF(nn.Module):
         of the random-draw tensors on the stochastic path.
 
         Extension for multi-GPU sharding: ``row_begin``/``row_end`` render only that block of
-        image rows (of every frame in the batch) and return [B, rows, W, .]."""
+        image rows (of every frame in the batch) and return [B, rows, W, .].
+
+        Like the reference's, the result is differentiable w.r.t. the parameters when gradients are enabled
+        (the reference has no ``no_grad`` inside, model.py:754-770; its callers wrap the call,
+        train_conditional_nerf.py:139): the frame then goes through ``render_rays`` chunk by chunk exactly as
+        the reference's loop does, every chunk keeping its training workspace (11 KB per sample) until the
+        backward.  Wrap inference in ``torch.no_grad()`` for the one-launch path."""
         _require_device(camera_o, "camera_o"), _require_device(camera_r, "camera_r")
         device = camera_o.device
         batch = camera_o.shape[0]
         row_end = image_h if row_end is None else row_end
         rows = row_end - row_begin
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # the reference's body (model.py:727-770) on the differentiable render_rays
+            rays = self.generate_rays(image_h, image_w, focal_length, dtype=camera_o.dtype, device=device)
+            rays = torch.broadcast_to(rays[row_begin:row_end].unsqueeze(0), [batch, rows, image_w, 3])
+            cam_o = torch.broadcast_to(camera_o[:, None, None, :], [batch, rows, image_w, 3])
+            cam_r = torch.broadcast_to(camera_r[:, None, None, :, :], [batch, rows, image_w, 3, 3])
+            rays_o, rays_d = self.rays_to_world_coordinates(rays, cam_o, cam_r)
+            rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+            step = max(int(max_chunk_size), 1)
+            parts = [self.render_rays(o_i, d_i, num_samples, randomly_sample=randomly_sample,
+                                      density_noise_std=density_noise_std)
+                     for o_i, d_i in zip(torch.split(rays_o, step), torch.split(rays_d, step))]
+            return (torch.cat([p[0][:, -1] for p in parts]).reshape(batch, rows, image_w, self.color_outputs),
+                    torch.cat([p[1][:, -1] for p in parts]).reshape(batch, rows, image_w,
+                                                                    self.segmentation_outputs))
         cam_o = camera_o.detach().contiguous()
         cam_r = camera_r.detach().contiguous()
         cameras = (cam_o, cam_r, image_h, image_w, focal_length)

@@ -213,3 +213,32 @@ def test_gradients_of_a_batch_with_twelve_orders_of_dynamic_range(dev):
     for k, p in model.named_parameters():
         e = rel_err(p.grad.cpu(), ref[k].grad)
         assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+
+
+def test_render_image_is_differentiable_like_the_reference(dev):
+    """The reference's render_image builds an autograd graph (no ``no_grad`` inside, nerf/model.py:754-770):
+    gradients of a loss on a small frame against the oracle's autograd through ITS render_image, and the
+    no-grad path renders the same pixels."""
+    params = golden_params(2.0)
+    cam_o = torch.tensor([[0.0, -3.0, 2.6], [2.0, 2.0, 1.5]])
+    cam_r = torch.cat([O.look_at_pose(c.tolist()) for c in cam_o])
+    H, W, S, focal = 6, 5, 24, 6.2
+    gen = torch.Generator().manual_seed(3)
+    w_img = torch.randn(2, H, W, 3, generator=gen)
+    cfg = dict(CFG, focal_length=112.0)
+    ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    img_r, seg_r = O.render_image(ref, cfg, cam_o, cam_r, H, W, focal, S, max_chunk_size=16)
+    (img_r * w_img).sum().backward()
+    exact = fp64_gradients(params, lambda p: (O.render_image(p, cfg, cam_o.double(), cam_r.double(), H, W, focal, S)[0]
+                                              * w_img.double()).sum())
+    model = make_model(dev, params)
+    img, seg = model.render_image(cam_o.to(dev), cam_r.to(dev), H, W, focal, S, max_chunk_size=16)
+    assert img.requires_grad and img.shape == (2, H, W, 3) and seg.shape == (2, H, W, 50)
+    (img * w_img.to(dev)).sum().backward()
+    with torch.no_grad():
+        plain, _ = model.render_image(cam_o.to(dev), cam_r.to(dev), H, W, focal, S)
+    assert not plain.requires_grad and (plain - img.detach()).abs().max() <= 2e-6
+    noise_floor = max(rel_err(ref[k].grad, exact[k]) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad.cpu(), ref[k].grad)
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)

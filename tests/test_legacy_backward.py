@@ -256,12 +256,12 @@ def test_forty_training_steps_on_the_checkpoints_scene_track_the_oracle(graph):
 
 @pytest.mark.gpu
 def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameters():
-    """The conditioning-free version of the trajectory test: along the oracle's own 24-step training run on the
+    """The conditioning-free version of the trajectory test: along the oracle's own 16-step training run on the
     same scene, the HIP model is given the oracle's parameters before EVERY step; the loss must agree to 1e-5
     relative at every step and, every eighth step, all 44 gradients within the rule of the gradient tests."""
     from nerf_amd import trainer as T
     dev = torch.device("cuda:0")
-    steps, batch, S, lr, size = 24, 256, 32, 5e-4, 16
+    steps, batch, S, lr, size = 16, 256, 32, 5e-4, 16
     images, poses, focal = lego_scene(dev, size)
     data = T.PixelRayDataset(images[:-1], torch.zeros(5, size, size, dtype=torch.int64, device=dev), poses[:-1], focal)
     params0 = L.init_params(seed=5)
