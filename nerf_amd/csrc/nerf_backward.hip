@@ -210,13 +210,15 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
             }
 #pragma unroll 1
             for (int L = 4; L >= 0; --L) {
-                // (the next LayerNorm backward's saved tile rides along: load T behind save T, 33 vector-memory
-                //  operations in all, every one younger than the two stages this layer's loop opens first)
-                const float* xrow_n = L > 0 ? ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g : nullptr;
                 layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                           ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
-                                          turn, unscale, xrow_n);
+                                          turn, unscale);
                 if (L == 0) break;                // dy[0] feeds only the weight gradient
+                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
+                // all of them younger than the two stages this layer's loop opens first
+                const float* xrow_n = ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g;
+#pragma unroll
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);
                 rstd = ws[ba.L.rstd[L - 1] + sp];
                 // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
                 // workgroup's maximum) the weight-gradient kernel's

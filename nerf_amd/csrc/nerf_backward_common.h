@@ -61,15 +61,12 @@ struct BwdHook {
 //   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
 //   kScaled (split-precision chain): acc holds dL/dx times the per-sample power of two `unscale`
 //   undoes (the B operands were scaled into the f16 range, the weights carry 2^kWScaleLog2)
-//   xhat_next (split-precision chain): the saved x_hat row of the NEXT LayerNorm backward; its tile T is
-//   loaded into xh[T] as soon as pass 2 has finished with this layer's tile T, so the 16 loads go out
-//   interleaved with the 16 dY saves and have the rest of the pass to fly
 template <bool kScaled = false>
 __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
                                                     f32x4 (&acc)[16], float (&act)[64],
-                                                    f32x4 (&xh)[16], float rstd,
+                                                    const f32x4 (&xh)[16], float rstd,
                                                     float* dy_row, float* gb_l, GammaBetaTurn& turn,
-                                                    float unscale = 1.0f, const float* xhat_next = nullptr) {
+                                                    float unscale = 1.0f) {
     const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     float s1 = 0.f, s2 = 0.f;
@@ -121,7 +118,6 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             act[4 * T + r] = dy[r];
         }
         *(f32x4*)(dy_row + T * 16) = dy;
-        if (kScaled && xhat_next != nullptr) xh[T] = *(const f32x4*)(xhat_next + T * 16);
     }
 }
 
