@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "nerf_device.h"
+#include "nerf_fused.h"
 #include "nerf_legacy_layout.h"
 
 using namespace nerf_layout;
@@ -28,7 +29,7 @@ using namespace nerf_legacy;
 namespace {
 
 constexpr int kLegacySmallBytes = (kLegacySmallFloats * 4 + 127) / 128 * 128;
-constexpr int kLegacyLdsBytes = kRingBytes + kLegacySmallBytes;                // 79,104 B -> 2 workgroups / CU
+constexpr int kLegacyLdsBytes = kRingBytes + kLegacySmallBytes;                // 80,000 B -> 2 workgroups / CU
 
 struct LegacyKernelArgs {
     NerfHipLegacyArgs l;
@@ -325,48 +326,28 @@ __global__ __launch_bounds__(256) void nerf_legacy_composite_fwd_kernel(const Le
 // ---------------------------------------------------------------------------------------------
 // The same launch in split-precision arithmetic (LegacyNeRF8x256.precision = "f16x3"): every fp32
 // operand of the twelve matrix products as an f16 pair, three v_mfma_f32_16x16x32_f16 per product, fp32
-// accumulation (layer_wide_h of nerf_device.h: the data gradient's loop, B operands split up front).
-// Accumulators hold 2^12 (W x + b); ReLU and LayerNorm run on them with eps * 2^24 (bit-identical
-// x_hat); gamma / beta come pre-scaled by 2^4 so the next layer's operands are already in range.
+// accumulation.  The ten wide layers run on the main kernel's fused layer (nerf_fused.h: layer_fused_h in
+// the Linear -> ReLU -> LayerNorm order): the LayerNorm is NOT a VALU phase between two loops — the moments of
+// relu(y) are gathered while the second half of the layer runs, and gamma a_hat + beta of the next layer's
+// input is applied lazily and split into f16 pairs one stage ahead of the stage that consumes it.
+// Accumulators hold 2^12 (W x + b) (eps * 2^24, bit-identical a_hat); gamma / beta come pre-scaled by 2^4.
+//   * X and Y swap roles layer by layer (no copy-back): L0: X (encoding) -> Y, L1: Y -> X, ... L9: Y -> X.
+//   * L4 / L8 = the fused layer over the hidden columns + a short loop (layer_wide_h<2>) over the two k blocks
+//     of the concatenated encoding, which is RE-ENCODED right there (15 / 9 sines per lane) rather than held in
+//     16 registers across four layers; their moments are gathered after that loop.
+//   * the density head runs after L8's loops on x'_7, which L8's fused loop has normalised in place; the
+//     color head normalises y_9 on the fly.  Both split their operands block by block between the MFMAs.
+//   * the per-ray compositing state (4 sums, the sample spacing) and the ray wait in 1.4 KiB of LDS while the
+//     MLP runs, so that nothing is spilled (the state is the same in all four lane groups: 16 slots per wave).
 // ---------------------------------------------------------------------------------------------
-// (the normalised activations leave as the next layer's B operands, k block m = tiles 2m, 2m + 1)
-__device__ __forceinline__ void relu_layer_norm_h(const f32x4 (&acc)[16], const float* small_l, int g,
-                                                  h8 (&bh)[8], h8 (&bl)[8]) {
-    float act[64];
-    float sum = 0.f;
-#pragma unroll
-    for (int T = 0; T < 16; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
-            sum += act[4 * T + r];
-        }
-    const float mean = group_sum(sum) * (1.0f / 256.0f);
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const float d = act[i] - mean;
-        sq = __builtin_fmaf(d, d, sq);
-    }
-    constexpr float kEps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) * (float)(1 << (kWScaleLog2 + kXScaleLog2));
-    const float ve = group_sum(sq) * (1.0f / 256.0f) + kEps;
-    float rstd = __builtin_amdgcn_rsqf(ve);
-    rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-    const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
-    const f32x4* bet = (const f32x4*)(small_l + 2 * kHidden + g * 64);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        f32x4 y[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int T = 2 * m + h;
-            const f32x4 ga = gam[T], be = bet[T];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[h][r] = __builtin_fmaf((act[4 * T + r] - mean) * rstd, ga[r], be[r]);
-        }
-        split8(y[0], y[1], bh[m], bl[m]);
-    }
-}
+constexpr int kLegacyStashBytes = kWavesPerWg * 16 * (4 + 1) * 4;  // per sample slot of a wave: 4 sums + the spacing
+constexpr int kLegacyRayStashBytes = kWavesPerWg * 8 * 4;
+constexpr int kLegacyLdsBytesHalf = kLegacyLdsBytes + kLegacyStashBytes + kLegacyRayStashBytes;   // 81,408 B: still 2 / CU
+static_assert(2 * kLegacyLdsBytesHalf <= 160 * 1024, "two workgroups per CU");
+
+using nerf_fused::HMoments;
+using nerf_fused::LazyNorm;
+using nerf_fused::kOrderReluNorm;
 
 // k block m of a 64-register activation tile set = tiles 2m, 2m + 1 -> an f16-pair B operand
 __device__ __forceinline__ void split_block(const float (&act)[64], int m, h8& hi, h8& lo) {
@@ -374,22 +355,32 @@ __device__ __forceinline__ void split_block(const float (&act)[64], int m, h8& h
            f32x4{act[8 * m + 4], act[8 * m + 5], act[8 * m + 6], act[8 * m + 7]}, hi, lo);
 }
 
-// one-tile head: one stage = pair i = (out tile 0, k block i)
-__device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, const h8 (&bh)[8], const h8 (&bl)[8]) {
+// One-tile head (256 -> <= 16 outputs) on f16 pairs straight from the fp32 activation tiles: one stage = pair
+// i = (out tile 0, k block i); block i = tiles 2i, 2i + 1 is normalised (kNorm: the tiles still hold raw
+// accumulators) and split right in front of its three MFMAs, its weights read one block ahead.
+template <bool kNorm>
+__device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, f32x4 (&x)[16], const LazyNorm& norm) {
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.open_stage();
-    h8 ah[8], al[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        ah[m] = st[(2 * m) * 64];
-        al[m] = st[(2 * m + 1) * 64];
-    }
+    h8 ah[2], al[2];
+    ah[0] = st[0];
+    al[0] = st[64];
     pipe.prefetch_next();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        acc = mfma_h(ah[m], bh[m], acc);
-        acc = mfma_h(ah[m], bl[m], acc);
-        acc = mfma_h(al[m], bh[m], acc);
+        if (m + 1 < 8) {
+            ah[(m + 1) & 1] = st[(2 * m + 2) * 64];
+            al[(m + 1) & 1] = st[(2 * m + 3) * 64];
+        }
+        if (kNorm) {
+            nerf_fused::normalize_tile<false, false, kOrderReluNorm>(x[2 * m], norm, 2 * m);
+            nerf_fused::normalize_tile<false, false, kOrderReluNorm>(x[2 * m + 1], norm, 2 * m + 1);
+        }
+        h8 bh, bl;
+        split8(x[2 * m], x[2 * m + 1], bh, bl);
+        acc = mfma_h(ah[m & 1], bh, acc);
+        acc = mfma_h(ah[m & 1], bl, acc);
+        acc = mfma_h(al[m & 1], bh, acc);
     }
     __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
     return acc;
@@ -404,92 +395,118 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
     const int j = lane & 15, g = lane >> 4;
     const int S = a.num_samples;
     constexpr float kX = (float)(1 << kXScaleLog2), kUn = 1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2));
+    constexpr float kEps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) * (float)(1 << (kWScaleLog2 + kXScaleLog2));
 
     float* small = (float*)(smem + kRingBytes);
     for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyHSmallOffset + i];
+    f32x4* const stash = (f32x4*)(smem + kLegacyLdsBytes) + (wave * 16 + j);          // this sample slot: 4 sums ...
+    float* const stash_dist = (float*)(smem + kLegacyLdsBytes + kWavesPerWg * 16 * 16) + (wave * 16 + j);   // ... spacing
+    float* const ray_stash = (float*)(smem + kLegacyLdsBytes + kLegacyStashBytes) + wave * 8;
     LegacyHPipe pipe;
     pipe.init(a.packed + kLegacyHOffset, smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();
 
+    auto gamma_of = [&](const float* sl) { return (const f32x4*)(sl + kHidden + g * 64); };
+    auto beta_of = [&](const float* sl) { return (const f32x4*)(sl + 2 * kHidden + g * 64); };
+
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
         int64_t local = grp * kWavesPerWg + wave;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
-        const Ray ray = load_ray(a, local);
-        const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
-        h8 dir_h[2], dir_l[2];                    // the encoded view direction as two k blocks, once per ray
         {
-            float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
-            if (la.normalize_directions) {
-                const float inv = 1.0f / dlen;
-                dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
+            const Ray ray = load_ray(a, local);
+            if (lane == 0) {
+                *(f32x4*)ray_stash = f32x4{ray.o[0], ray.o[1], ray.o[2], ray.d[0]};
+                ray_stash[4] = ray.d[1];
+                ray_stash[5] = ray.d[2];
             }
-            float dir_act[64];
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                dir_act[q] = q < kDirPerGroup ? kX * encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
-            split_block(dir_act, 0, dir_h[0], dir_l[0]);
-            split_block(dir_act, 1, dir_h[1], dir_l[1]);
         }
+        asm volatile("" ::: "memory");            // the reads of the stash below stay below
         RayAccum racc;
         racc.reset();
         for (int c = 0; c < ka.chunks; ++c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = s < S;
             const int sc = s < S - 1 ? s : S - 1;
-            const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
-            const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
-            h8 pos_h[2], pos_l[2];
+            auto the_ray = [&]() {                // the wave's ray, back from LDS (broadcast reads)
+                Ray r;
+                const f32x4 r0 = *(const f32x4*)ray_stash;
+                r.o[0] = r0.x, r.o[1] = r0.y, r.o[2] = r0.z, r.d[0] = r0.w;
+                r.d[1] = ray_stash[4], r.d[2] = ray_stash[5];
+                return r;
+            };
+            f32x4 X[16], Y[16];                   // a layer's input tiles (B operands) / its accumulators, in turn
             {
+                const Ray ray = the_ray();
+                const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
+                const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
+                const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
+                if (g == 0) {
+                    *stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
+                    *stash_dist = dist;
+                }
                 float pos_act[64];
-                {
-#pragma clang fp contract(off)
-                    const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
-                                        (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
-                                        (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
+                encode_position(ray, t0, la, g, pos_act);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        pos_act[q] = q < kPosPerGroup ? kX * encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
-                }
-                split_block(pos_act, 0, pos_h[0], pos_l[0]);
-                split_block(pos_act, 1, pos_h[1], pos_l[1]);
+                for (int t = 0; t < kPosTiles; ++t)
+                    X[t] = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]} * kX;
             }
-            f32x4 acc[16];
-            h8 bh[10], bl[10];                    // B operands: k blocks 0..7 = hidden activations, 8..9 = an encoding
-            // ---- block_0 ----
-            load_bias(small, g, acc);
-            layer_wide_h<2, 0>(pipe, acc, pos_h, pos_l);
-            relu_layer_norm_h(acc, small, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
+            LazyNorm norm;
+            HMoments mom;
+            // ---- L0: X (encoded position, 2 k blocks) -> Y ----
+            load_bias(small, g, Y);
+            nerf_fused::layer_fused_h<2, false, false, kOrderReluNorm>(pipe, X, Y, norm, mom);
+            norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(small), beta_of(small),
+                                                                                   g, nullptr, nullptr, kEps);
+            f32x4 dens;
+            // ---- L1 .. L9 in pairs (Y -> X, X -> Y): one code instance per direction ----
 #pragma unroll 1
-            for (int L = 1; L <= 7; ++L) {
-                const float* sl = small + L * kLegacySmallPerLayer;
-                load_bias(sl, g, acc);
-                if (L == 4) {                     // block_1's first layer: [hidden | encoded position]
-                    bh[8] = pos_h[0], bl[8] = pos_l[0], bh[9] = pos_h[1], bl[9] = pos_l[1];
-                    layer_wide_h<10, 0>(pipe, acc, bh, bl);
-                } else {
-                    layer_wide_h<8, 0>(pipe, acc, *(h8(*)[8])bh, *(h8(*)[8])bl);
+            for (int p = 0; p < 5; ++p) {
+                const float* sa = small + (2 * p + 1) * kLegacySmallPerLayer;         // L1, L3, L5, L7, L9
+                load_bias(sa, g, X);
+                nerf_fused::layer_fused_h<8, true, false, kOrderReluNorm>(pipe, Y, X, norm, mom);
+                norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, X, gamma_of(sa), beta_of(sa), g,
+                                                                                       nullptr, nullptr, kEps);
+                if (p == 4) break;
+                const float* sb = sa + kLegacySmallPerLayer;                          // L2, L4, L6, L8
+                load_bias(sb, g, Y);
+                nerf_fused::layer_fused_h<8, true, false, kOrderReluNorm>(pipe, X, Y, norm, mom);
+                if (p & 1) {
+                    // L4: + [encoded position], L8: + [encoded direction]: two more k blocks, encoded here
+                    h8 eh[2], el[2];
+                    {
+                        const Ray ray = the_ray();
+                        float enc[64];
+                        if (p == 1) encode_position(ray, fencepost(a, local, sc), la, g, enc);
+                        else encode_direction(ray, __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]),
+                                              la, g, enc);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) enc[q] = (p == 1 || q < 4 * kDirTiles) ? enc[q] * kX : 0.f;
+                        split_block(enc, 0, eh[0], el[0]);
+                        split_block(enc, 1, eh[1], el[1]);
+                    }
+                    layer_wide_h<2, 0>(pipe, Y, eh, el);
+                    mom.reset();
+#pragma unroll
+                    for (int T = 0; T < 16; ++T) mom.template add<kOrderReluNorm>(Y[T]);
+                    if (p == 3) {                 // density head on x'_7 (normalised in place by L8's fused loop)
+                        const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
+                        dens = head_layer_h<false>(pipe, hb[g], X, norm) * kUn;
+                    }
                 }
-                relu_layer_norm_h(acc, sl, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
+                norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(sb), beta_of(sb), g,
+                                                                                       nullptr, nullptr, kEps);
             }
-            // ---- density head ----
             const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-            const f32x4 dens = head_layer_h(pipe, hb[g], *(h8(*)[8])bh, *(h8(*)[8])bl) * kUn;
-            // ---- block_2: [hidden | encoded direction] -> 256 -> 256 ----
+            const f32x4 col = head_layer_h<true>(pipe, hb[4 + g], X, norm) * kUn;
+            float dist;
             {
-                const float* sl = small + 8 * kLegacySmallPerLayer;
-                load_bias(sl, g, acc);
-                bh[8] = dir_h[0], bl[8] = dir_l[0], bh[9] = dir_h[1], bl[9] = dir_l[1];
-                layer_wide_h<10, 0>(pipe, acc, bh, bl);
-                relu_layer_norm_h(acc, sl, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
-                const float* sl9 = small + 9 * kLegacySmallPerLayer;
-                load_bias(sl9, g, acc);
-                layer_wide_h<8, 0>(pipe, acc, *(h8(*)[8])bh, *(h8(*)[8])bl);
-                relu_layer_norm_h(acc, sl9, g, *(h8(*)[8])bh, *(h8(*)[8])bl);
+                const f32x4 s0 = *stash;
+                racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
+                dist = *stash_dist;
             }
-            const f32x4 col = head_layer_h(pipe, hb[4 + g], *(h8(*)[8])bh, *(h8(*)[8])bl) * kUn;
             f32x4 out[4];
             out[0] = f32x4{dens.x, col.x, col.y, col.z};
             out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -587,8 +604,16 @@ __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
                     first = h_stage_of_layer(L);
                     if (stage >= first && stage < first + 2 * wide_blocks(L)) break;
                 }
+                // 8-block layers: stage (half, m) = half * 8 + m.  L4 / L8 (10 blocks): the 16 stages of the hidden
+                // blocks first, then 4 stages (half, m - 8) of the two encoding blocks (their own short loop)
                 const int KB = wide_blocks(L), sl = stage - first;
-                const int half = sl / KB, m = sl % KB;
+                int half, m;
+                if (KB == 10) {
+                    half = sl < 16 ? sl / 8 : (sl - 16) / 2;
+                    m = sl < 16 ? sl % 8 : 8 + (sl - 16) % 2;
+                } else {
+                    half = sl / KB, m = sl % KB;
+                }
                 const int out = 16 * (8 * half + pair) + row;
                 const int tt = 2 * m + (jj >> 2);             // register tile of the B operand
                 const int K = wide_inputs(L);
@@ -733,7 +758,7 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: unknown precision");
     const bool half = a.precision == NERF_HIP_PRECISION_F16X3;
     static unsigned done = 0, done_h = 0, done_t = 0;
-    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_h_kernel, kLegacyLdsBytes, device, &done_h)
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_h_kernel, kLegacyLdsBytesHalf, device, &done_h)
         : train ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<true>, kLegacyLdsBytes, device, &done_t)
                 : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<false>, kLegacyLdsBytes, device, &done);
     if (rc) return rc;
@@ -741,7 +766,7 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    if (half) hipLaunchKernelGGL(nerf_legacy_fwd_h_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    if (half) hipLaunchKernelGGL(nerf_legacy_fwd_h_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytesHalf, st, ka);
     else if (train) {
         hipLaunchKernelGGL(nerf_legacy_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;

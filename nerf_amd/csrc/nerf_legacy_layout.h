@@ -76,12 +76,14 @@ __host__ __device__ inline int bwd_layer_of_stage(int s, int& tout) {
     return 9 - w / 16;
 }
 
+// f16 image, consumption order: L0 .. L7, L8 (hidden blocks, then its two encoding blocks), density head,
+// L9, color head (the density head runs AFTER L8's loops there: L8's fused loop is what normalises x'_7)
 __host__ __device__ inline int h_stage_of_layer(int L) {    // first stage of wide layer L in the f16 image
     int s = 0;
     for (int i = 0; i < L; ++i) s += 2 * wide_blocks(i);
-    return s + (L >= 8 ? 1 : 0);
+    return s + (L >= 9 ? 1 : 0);
 }
-constexpr int kHDensityStage = 4 + 3 * 16 + 20 + 3 * 16;     // 120
+constexpr int kHDensityStage = 4 + 3 * 16 + 20 + 3 * 16 + 20;     // 140
 constexpr int kHColorStage = kLegacyHStages - 1;
 __host__ __device__ inline int stage_of_layer(int L) {      // first stage of wide layer L
     int s = 0;
