@@ -709,7 +709,8 @@ struct RayAccum {
 // out[T][r] = padded network output n = 16 T + 4 g + r of sample s = 16 c + j (accumulator
 // layout); returns the compositing weight of the sample.  `comp` (training): where this sample's
 // (alpha, T_exclusive, dist, density + noise) goes.
-template <bool kSave>
+// kSeg = false: a network without segmentation classes (the legacy network) — no class state is kept or updated.
+template <bool kSave, bool kSeg = true>
 __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int P, int64_t local, int s,
                                                  bool ok, int lane, const f32x4 (&out)[4], float dist,
                                                  RayAccum& acc, float* comp) {
@@ -743,8 +744,8 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
     acc.rgb1 += row_sum(cg);
     acc.rgb2 += row_sum(cb);
 
-    if (a.seg != nullptr) {
-        // log_softmax over the 50 class logits of this sample
+    if (kSeg && a.seg != nullptr) {
+        // log_softmax over the class logits of this sample
         float m = -__builtin_inff();
 #pragma unroll
         for (int T = 0; T < 4; ++T)
@@ -784,6 +785,7 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
 }
 
 // one coalesced store instruction per output row
+template <bool kSeg = true>
 __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t local, bool ray_ok, int lane,
                                           const RayAccum& acc) {
     // lane 0 stores the three sums (a per-lane select of acc.rgb0/1/2 by lane id makes the compiler
@@ -794,8 +796,8 @@ __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t lo
         a.rgb[local * 3 + 1] = acc.rgb1;
         a.rgb[local * 3 + 2] = acc.rgb2;
     }
-    if (a.seg != nullptr) {
-        // the wave's 64 lanes cover n = 0..63 once: the 50 class values leave in one store
+    if (kSeg && a.seg != nullptr) {
+        // the wave's 64 lanes cover n = 0..63 once: the class values leave in one store
         const int j = lane & 15, g = lane >> 4;
         const float mine = acc.seg_m + logf(acc.seg_s);
         const int n = 16 * (j >> 2) + 4 * g + (j & 3);

@@ -59,38 +59,45 @@ __device__ __forceinline__ float sincos_reduced(float y, bool cosine) {
     return ((int)n & 1) ? -p : p;
 }
 
-// Encoding feature f of [x: sin f_0..f_{F-1}, cos f_0..f_{F-1} | y: ... | z: ...] (nerf/model.py:233-240)
-template <int kFreqs>
-__device__ __forceinline__ float encoding_feature(int f, const float (&x)[3], float multiplier) {
-    const int coord = f / (2 * kFreqs), within = f - coord * 2 * kFreqs;
-    const bool cosine = within >= kFreqs;
-    const int k = cosine ? within - kFreqs : within;
-    const float v = coord == 0 ? x[0] : (coord == 1 ? x[1] : x[2]);
-    return sincos_reduced(v * (multiplier * (float)(1 << k)), cosine);
+// This lane group's slots of an encoding [x: sin f_0..f_{F-1}, cos f_0..f_{F-1} | y: ... | z: ...]
+// (nerf/model.py:233-240), f_k = multiplier 2^k: slot q = half * coord + kk is the lane group's trig function
+// (g >> 1) of coordinate q / half at frequency 2^kk times the group's base frequency (nerf_legacy_layout.h:
+// encoding_feature_of).  The argument v * (multiplier * 2^k) is rounded exactly as in the oracle (the extra
+// factors are powers of two).
+template <int kFreqs, int kSlots>
+__device__ __forceinline__ void encode_slots(const float (&x)[3], float multiplier, int g, float scale,
+                                             float (&out)[64]) {
+    constexpr int kHalf = kFreqs / 2;
+    const float base = (g & 1) ? multiplier * (float)(1 << kHalf) : multiplier;
+    const bool cosine = (g >> 1) != 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (q < kSlots) {
+            const float v = q / kHalf == 0 ? x[0] : (q / kHalf == 1 ? x[1] : x[2]);
+            out[q] = scale * sincos_reduced(v * (base * (float)(1 << (q % kHalf))), cosine);
+        } else {
+            out[q] = 0.f;
+        }
+    }
 }
-
-// This lane group's slots of the two encodings (15 of 60 position features in 16 slots, 9 of 36 direction
-// features in 12): PE(position / normalize_position) at the sample t0 along the ray, PE(d / |d|).
+// PE(position / normalize_position) at the sample t0 along the ray (15 of 60 features per lane group in 16
+// slots) and PE(d / |d|) (9 of 36 in 12 slots; 16 written), times `scale`
 __device__ __forceinline__ void encode_position(const Ray& ray, float t0, const NerfHipLegacyArgs& la, int g,
-                                                float (&pos_act)[64]) {
+                                                float (&pos_act)[64], float scale = 1.0f) {
 #pragma clang fp contract(off)
     const float x[3] = {(ray.d[0] * t0 + ray.o[0]) / la.normalize_position,
                         (ray.d[1] * t0 + ray.o[1]) / la.normalize_position,
                         (ray.d[2] * t0 + ray.o[2]) / la.normalize_position};
-#pragma unroll
-    for (int q = 0; q < 4 * kPosTiles; ++q)
-        pos_act[q] = q < kPosPerGroup ? encoding_feature<kPosFreqs>(kPosPerGroup * g + q, x, la.multiplier) : 0.f;
+    encode_slots<kPosFreqs, kPosPerGroup>(x, la.multiplier, g, scale, pos_act);
 }
 __device__ __forceinline__ void encode_direction(const Ray& ray, float dlen, const NerfHipLegacyArgs& la, int g,
-                                                 float (&dir_act)[64]) {
+                                                 float (&dir_act)[64], float scale = 1.0f) {
     float dn[3] = {ray.d[0], ray.d[1], ray.d[2]};
     if (la.normalize_directions) {
         const float inv = 1.0f / dlen;
         dn[0] *= inv, dn[1] *= inv, dn[2] *= inv;
     }
-#pragma unroll
-    for (int q = 0; q < 4 * kDirTiles; ++q)
-        dir_act[q] = q < kDirPerGroup ? encoding_feature<kDirFreqs>(kDirPerGroup * g + q, dn, la.multiplier) : 0.f;
+    encode_slots<kDirFreqs, kDirPerGroup>(dn, la.multiplier, g, scale, dir_act);
 }
 
 // LayerNorm(256, eps 1e-5, affine) of relu(acc) -> act (the next layer's B operands).
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
                 for (int T = 0; T < 4; ++T) *(f32x4*)(otile + T * 256) = out[T];
                 continue;
             }
-            const float w = composite_chunk<false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
+            const float w = composite_chunk<false, false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
             if (ray_ok && ok && g == 0) {
                 const int64_t smp = local * S + s;
                 if (a.out_weights != nullptr) a.out_weights[smp] = w;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
                 }
             }
         }
-        if (!kTrain) store_ray(a, local, ray_ok, lane, racc);
+        if (!kTrain) store_ray<false>(a, local, ray_ok, lane, racc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -431,6 +438,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
             const bool ok = s < S;
             const int sc = s < S - 1 ? s : S - 1;
             auto the_ray = [&]() {                // the wave's ray, back from LDS (broadcast reads)
+                // (a compiler barrier: otherwise the reads, and the 24 sine arguments of the direction that depend
+                //  only on them, are hoisted out of the chunk loop and then spilled across every layer)
+                asm volatile("" ::: "memory");
                 Ray r;
                 const f32x4 r0 = *(const f32x4*)ray_stash;
                 r.o[0] = r0.x, r.o[1] = r0.y, r.o[2] = r0.z, r.d[0] = r0.w;
@@ -448,10 +458,10 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     *stash_dist = dist;
                 }
                 float pos_act[64];
-                encode_position(ray, t0, la, g, pos_act);
+                encode_position(ray, t0, la, g, pos_act, kX);
 #pragma unroll
                 for (int t = 0; t < kPosTiles; ++t)
-                    X[t] = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]} * kX;
+                    X[t] = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]};
             }
             LazyNorm norm;
             HMoments mom;
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
             nerf_fused::layer_fused_h<2, false, false, kOrderReluNorm>(pipe, X, Y, norm, mom);
             norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(small), beta_of(small),
                                                                                    g, nullptr, nullptr, kEps);
-            f32x4 dens;
+            float dens = 0.f;
             // ---- L1 .. L9 in pairs (Y -> X, X -> Y): one code instance per direction ----
 #pragma unroll 1
             for (int p = 0; p < 5; ++p) {
@@ -479,11 +489,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     {
                         const Ray ray = the_ray();
                         float enc[64];
-                        if (p == 1) encode_position(ray, fencepost(a, local, sc), la, g, enc);
+                        if (p == 1) encode_position(ray, fencepost(a, local, sc), la, g, enc, kX);
                         else encode_direction(ray, __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]),
-                                              la, g, enc);
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) enc[q] = (p == 1 || q < 4 * kDirTiles) ? enc[q] * kX : 0.f;
+                                              la, g, enc, kX);
                         split_block(enc, 0, eh[0], el[0]);
                         split_block(enc, 1, eh[1], el[1]);
                     }
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     for (int T = 0; T < 16; ++T) mom.template add<kOrderReluNorm>(Y[T]);
                     if (p == 3) {                 // density head on x'_7 (normalised in place by L8's fused loop)
                         const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-                        dens = head_layer_h<false>(pipe, hb[g], X, norm) * kUn;
+                        dens = head_layer_h<false>(pipe, hb[g], X, norm).x * kUn;
                     }
                 }
                 norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(sb), beta_of(sb), g,
@@ -508,21 +516,21 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 dist = *stash_dist;
             }
             f32x4 out[4];
-            out[0] = f32x4{dens.x, col.x, col.y, col.z};
+            out[0] = f32x4{dens, col.x, col.y, col.z};
             out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float w = composite_chunk<false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
+            const float w = composite_chunk<false, false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
             if (ray_ok && ok && g == 0) {
                 const int64_t smp = local * S + s;
                 if (a.out_weights != nullptr) a.out_weights[smp] = w;
                 if (a.out_raw != nullptr) {
-                    a.out_raw[smp * 4 + 0] = dens.x;
+                    a.out_raw[smp * 4 + 0] = dens;
                     a.out_raw[smp * 4 + 1] = col.x;
                     a.out_raw[smp * 4 + 2] = col.y;
                     a.out_raw[smp * 4 + 3] = col.z;
                 }
             }
         }
-        store_ray(a, local, ray_ok, lane, racc);
+        store_ray<false>(a, local, ray_ok, lane, racc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -620,13 +628,13 @@ __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
                 int col = -1;
                 if (L == 0) {
                     const int q = 4 * tt + r;
-                    if (q < kPosPerGroup) col = kPosPerGroup * kg + q;
+                    if (q < kPosPerGroup) col = encoding_feature_of(kg, q, kPosFreqs);
                 } else if (tt < 16) {
                     col = 16 * tt + 4 * kg + r;
                 } else {
                     const int q = 4 * (tt - 16) + r;
-                    if (L == 4 && q < kPosPerGroup) col = kHidden + kPosPerGroup * kg + q;
-                    if (L == 8 && q < kDirPerGroup) col = kHidden + kDirPerGroup * kg + q;
+                    if (L == 4 && q < kPosPerGroup) col = kHidden + encoding_feature_of(kg, q, kPosFreqs);
+                    if (L == 8 && q < kDirPerGroup) col = kHidden + encoding_feature_of(kg, q, kDirFreqs);
                 }
                 if (col >= 0) w = pa.p[wide_param(L)][out * K + col];
             }
@@ -660,13 +668,13 @@ __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
             int col = -1;
             if (L == 0) {
                 const int q = 4 * t + r;
-                if (q < kPosPerGroup) col = kPosPerGroup * g + q;
+                if (q < kPosPerGroup) col = encoding_feature_of(g, q, kPosFreqs);
             } else if (t < 16) {
                 col = 16 * t + 4 * g + r;                   // hidden part: [hidden | encoding] order
             } else {
                 const int q = 4 * (t - 16) + r;
-                if (L == 4 && q < kPosPerGroup) col = kHidden + kPosPerGroup * g + q;
-                if (L == 8 && q < kDirPerGroup) col = kHidden + kDirPerGroup * g + q;
+                if (L == 4 && q < kPosPerGroup) col = kHidden + encoding_feature_of(g, q, kPosFreqs);
+                if (L == 8 && q < kDirPerGroup) col = kHidden + encoding_feature_of(g, q, kDirFreqs);
             }
             if (col >= 0) v = W[out * K + col];
         }

@@ -320,10 +320,10 @@ __global__ void nerf_legacy_grad_reduce_kernel(const LBwdArgs ba) {
         if (which == 1) so = kLSlabB + l * kHidden + idx;
         else {
             const int K = wide_inputs(l), row = idx / K, col = idx % K;
-            if (l == 0) so = kLSlabEnc + row * kEncPad + encoding_column(col, kPosPerGroup);
+            if (l == 0) so = kLSlabEnc + row * kEncPad + encoding_column(col, kPosFreqs);
             else if (col < kHidden) so = kLSlabHid + (l - 1) * kHidden * kHidden + row * kHidden + col;
-            else if (l == 4) so = kLSlabEnc + kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kPosPerGroup);
-            else so = kLSlabEnc + 2 * kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kDirPerGroup);
+            else if (l == 4) so = kLSlabEnc + kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kPosFreqs);
+            else so = kLSlabEnc + 2 * kHidden * kEncPad + row * kEncPad + encoding_column(col - kHidden, kDirFreqs);
         }
     }
     ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kLSlabFloats);

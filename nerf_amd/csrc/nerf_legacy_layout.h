@@ -99,10 +99,24 @@ __host__ __device__ inline int wide_inputs(int L) {
 }
 constexpr int kDensityW = 32, kDensityB = 33, kColorW = 42, kColorB = 43;
 
-// Column of encoding feature f (0..59 / 0..35) in a padded encoding row: lane group g holds features
-// per * g .. per * g + per - 1 in its slots q = 4 t + r, column 16 t + 4 g + r.
-__host__ __device__ inline int encoding_column(int f, int per_group) {
-    const int g = f / per_group, q = f % per_group;
+// Which encoding features a lane group computes.  The reference's layout (nerf/model.py:233-240) is, per
+// coordinate, [sin f_0 .. sin f_{F-1}, cos f_0 .. cos f_{F-1}], coordinate-major: feature = coord * 2F +
+// cos * F + k.  Lane group g takes, of every coordinate, the trig function g >> 1 (sine for groups 0, 1,
+// cosine for 2, 3) and the frequencies k = H (g & 1) + 0 .. H - 1 (H = F / 2: 5 position, 3 direction
+// frequencies), in slots q = H' coord + (k mod H) of its 15 (9) — so that coordinate and frequency offset of
+// a slot are compile-time constants and only ONE base frequency and ONE sin / cos choice depend on the lane
+// (a slot -> feature map that needs a division per lane makes the compiler keep two dozen lane-dependent
+// frequencies and flags alive across every loop of the kernels).
+__host__ __device__ inline int encoding_feature_of(int g, int q, int freqs) {     // slot q of lane group g
+    const int half = freqs / 2;
+    return (q / half) * 2 * freqs + (g >> 1) * freqs + half * (g & 1) + q % half;
+}
+// ... and back: column of feature f in a padded encoding row (lane group g, slot q = 4 t + r -> 16 t + 4 g + r)
+__host__ __device__ inline int encoding_column(int f, int freqs) {
+    const int half = freqs / 2;
+    const int coord = f / (2 * freqs), within = f % (2 * freqs);
+    const int cosine = within / freqs, k = within % freqs;
+    const int g = 2 * cosine + k / half, q = half * coord + k % half;
     return 16 * (q / 4) + 4 * g + (q % 4);
 }
 
