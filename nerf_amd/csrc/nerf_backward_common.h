@@ -88,20 +88,37 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             acc[T][r] = gdz;
         }
     };
-    // beta / gamma gradients: sums over the 16 samples of a row, lane j keeps tile j — a reduce-scatter
-    // butterfly (nerf_device.h: scatter_level8 / 4 / take) applied as the tiles come: t, t + 8, t + 4, t + 12
+    // beta / gamma gradients: sums over the 16 samples of a row, lane j keeps tile j.
     float kept[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (kScaled) {
+        // split-precision chain (VALU-paced): a reduce-scatter butterfly (nerf_device.h: scatter_level8 / 4 /
+        // take) applied as the tiles come: t, t + 8, t + 4, t + 12 — 2 DPP adds per value
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float va[8], vb[8], w0[8], w1[8], x[8];
-        tile(t, va);
-        tile(t + 8, vb);
-        scatter_level8(va, vb, w0);
-        tile(t + 4, va);
-        tile(t + 12, vb);
-        scatter_level8(va, vb, w1);
-        scatter_level4(w0, w1, x);
-        scatter_take(x, t, j, kept);
+        for (int t = 0; t < 4; ++t) {
+            float va[8], vb[8], w0[8], w1[8], x[8];
+            tile(t, va);
+            tile(t + 8, vb);
+            scatter_level8(va, vb, w0);
+            tile(t + 4, va);
+            tile(t + 12, vb);
+            scatter_level8(va, vb, w1);
+            scatter_level4(w0, w1, x);
+            scatter_take(x, t, j, kept);
+        }
+    } else {
+        // fp32 chain (matrix-paced: its MFMAs take four times as long): one row_sum per value; the butterfly's
+        // longer live ranges cost this kernel 120 B more spills than its shorter VALU phase gains
+        // (3.88 against 3.81 ms per 4096 x 64 step)
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            float v[8];
+            tile(T, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float sum = row_sum(v[i]);
+                if (j == T) kept[i] = sum;
+            }
+        }
     }
     const f32x4 keep_b = {kept[0], kept[1], kept[2], kept[3]}, keep_g = {kept[4], kept[5], kept[6], kept[7]};
     turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
