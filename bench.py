@@ -367,7 +367,7 @@ def baseline_configs(dev):
     return out
 
 
-def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2):
+def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, train_precision="fp32"):
     """One optimiser step of the notebook's training loop (examples/example.ipynb cell 8) on the LEGACY 8 x 256
     network, the one BASELINE config 5 / the PSNR target were published on: training forward + HIP backward
     (44 gradients) + fused Adam, 4096 rays x 64 samples, stratified draws, noise std 1.  fp32 MFMA forward and
@@ -375,6 +375,7 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2):
     from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE as LEGACY_FLOP
     torch.manual_seed(0)
     model = LegacyNeRF8x256().to(dev)
+    model.train_precision = train_precision
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     o = torch.randn(rays, 3, device=dev) * 0.5
     d = torch.randn(rays, 3, device=dev)
@@ -398,7 +399,9 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2):
     return {"workload": f"legacy 8x256 network, {rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": 3 * LEGACY_FLOP * rays * samples / dt / 1e12,
-            "arithmetic": "forward and data gradient on fp32 MFMA, weight gradient on bf16 triples; fp32 accumulate"}
+            "arithmetic": ("forward, data gradient and weight gradient on f16 pairs (three f16 MFMAs per product); fp32 "
+                           "accumulate" if train_precision == "f16x3" else
+                           "forward and data gradient on fp32 MFMA, weight gradient on bf16 triples; fp32 accumulate")}
 
 
 def profiled_traffic(precision):
@@ -598,6 +601,7 @@ def main():
             line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
             line["legacy_train_step"] = legacy_train_step_timing(dev)
+            line["legacy_train_step_f16x3"] = legacy_train_step_timing(dev, train_precision="f16x3")
             line["configs"] = baseline_configs(dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
     const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
-                      ba.data_grid};
+                      ba.data_grid, 8};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;       // [layer][bias | gamma | beta][256]
     if (job < 4) {                                // layers 1..4: input = LayerNorm+ReLU of layer job
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
     const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
-                      ba.data_grid};
+                      ba.data_grid, 8};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;
     if (job < 4) {

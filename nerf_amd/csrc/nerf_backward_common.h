@@ -469,8 +469,9 @@ struct WgradJob {
     int64_t tiles_per_split, n_tiles;             // 32-sample tiles per split, in all
     int split;
     float* slab;                                  // this split's partial slab
-    const float* dymax;                           // [data_grid][8] batch maxima of |dY| (f16 form), else unused
+    const float* dymax;                           // [data_grid][dymax_stride] batch maxima of |dY| (f16 form), else unused
     int data_grid;
+    int dymax_stride;
 };
 // kInput: what an X row holds — kInputRaw: the layer's input itself (encoded features);
 // kInputAffineRelu: the previous layer's saved x_hat, input = relu(gamma x_hat + beta) (the main network:
@@ -506,7 +507,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     float a_scale = 1.0f, un_scale = 1.0f;        // dY scale and what divides it (and X's) out again
     if (kF16) {
         float m = 0.f;
-        for (int q = threadIdx.x; q < ba.data_grid; q += 256) m = __builtin_fmaxf(m, ba.dymax[(int64_t)q * 8 + max_index]);
+        for (int q = threadIdx.x; q < ba.data_grid; q += 256) m = __builtin_fmaxf(m, ba.dymax[(int64_t)q * ba.dymax_stride + max_index]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
         float* red = (float*)smem;

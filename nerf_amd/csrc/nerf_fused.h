@@ -81,14 +81,16 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
                                                const f32x4& be) {
     f32x4 xh;
     if (kOrder == kOrderReluNorm) {
-        // (training saves of this order, with the exact-gate correction of nerf_legacy.hip: relu_layer_norm,
-        //  are not built: the legacy network trains in fp32 arithmetic)
-        static_assert(!(kTrain && kOrder == kOrderReluNorm), "no training saves in this order");
+        // training: a_hat is saved; the backward reads the ReLU gate as a_hat > shift (the a_hat of a == 0),
+        // so an OPEN gate whose a_hat rounds onto `shift` is moved one ulp up (nerf_legacy.hip: relu_layer_norm)
+        const float above = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, n.shift) - 1u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             xh[r] = __builtin_fmaf(__builtin_fmaxf(x[r], 0.f), n.rstd, n.shift);
+            if (kTrain) xh[r] = (x[r] > 0.f && xh[r] <= n.shift) ? above : xh[r];
             x[r] = __builtin_fmaf(xh[r], ga[r], be[r]);
         }
+        if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
         return;
     }
     if (kPacked) {
@@ -128,7 +130,7 @@ template <bool kTrain, class Mom, int kOrder = kOrderNormRelu>
 __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 (&raw)[16], const f32x4* gam,
                                                       const f32x4* bet, int g, float* save_row,
                                                       float* save_rstd, float eps = 1e-5f,
-                                                      float save_scale = 1.0f) {
+                                                      float save_scale = 1.0f, float* save_shift = nullptr) {
     const float mean = group_sum(m.sum()) * (1.0f / 256.0f);
     const float ex2 = group_sum(m.sum_sq()) * (1.0f / 256.0f);
     float var = ex2 - mean * mean;
@@ -151,6 +153,7 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
     LazyNorm n;
     n.rstd = rstd;
     n.shift = -mean * rstd;
+    if (kTrain && kOrder == kOrderReluNorm && g == 0) *save_shift = n.shift;      // (x_hat, so scale-free)
     n.gam = gam;
     n.bet = bet;
     n.save_row = save_row;

@@ -365,7 +365,7 @@ __device__ __forceinline__ void split_block(const float (&act)[64], int m, h8& h
 // One-tile head (256 -> <= 16 outputs) on f16 pairs straight from the fp32 activation tiles: one stage = pair
 // i = (out tile 0, k block i); block i = tiles 2i, 2i + 1 is normalised (kNorm: the tiles still hold raw
 // accumulators) and split right in front of its three MFMAs, its weights read one block ahead.
-template <bool kNorm>
+template <bool kNorm, bool kTrain>
 __device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, f32x4 (&x)[16], const LazyNorm& norm) {
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.open_stage();
@@ -380,8 +380,8 @@ __device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, f32x
             al[(m + 1) & 1] = st[(2 * m + 3) * 64];
         }
         if (kNorm) {
-            nerf_fused::normalize_tile<false, false, kOrderReluNorm>(x[2 * m], norm, 2 * m);
-            nerf_fused::normalize_tile<false, false, kOrderReluNorm>(x[2 * m + 1], norm, 2 * m + 1);
+            nerf_fused::normalize_tile<kTrain, false, kOrderReluNorm>(x[2 * m], norm, 2 * m);
+            nerf_fused::normalize_tile<kTrain, false, kOrderReluNorm>(x[2 * m + 1], norm, 2 * m + 1);
         }
         h8 bh, bl;
         split8(x[2 * m], x[2 * m + 1], bh, bl);
@@ -393,6 +393,11 @@ __device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, f32x
     return acc;
 }
 
+// kTrain: the training forward in this arithmetic (LegacyNeRF8x256.train_precision = "f16x3"): one (padded ray,
+// chunk) item per wave, compositing in its own kernel, the same saves as the fp32 training forward
+// (nerf_legacy_fwd_kernel<true>) into the same workspace — a_hat is scale-free, 1/std is un-scaled by 2^12 —
+// so that either backward arithmetic reads it.
+template <bool kTrain>
 __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyKernelArgs ka) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipLegacyArgs& la = ka.l;
@@ -401,8 +406,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int S = a.num_samples;
-    constexpr float kX = (float)(1 << kXScaleLog2), kUn = 1.0f / (float)(1 << (kWScaleLog2 + kXScaleLog2));
-    constexpr float kEps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) * (float)(1 << (kWScaleLog2 + kXScaleLog2));
+    float* const ws = a.train_workspace;
+    constexpr float kX = (float)(1 << kXScaleLog2), kRs = (float)(1 << (kWScaleLog2 + kXScaleLog2)), kUn = 1.0f / kRs;
+    constexpr float kEps = 1e-5f * kRs * kRs;
 
     float* small = (float*)(smem + kRingBytes);
     for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyHSmallOffset + i];
@@ -419,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
     auto beta_of = [&](const float* sl) { return (const f32x4*)(sl + 2 * kHidden + g * 64); };
 
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
-        int64_t local = grp * kWavesPerWg + wave;
+        const int64_t unit = grp * kWavesPerWg + wave;
+        const int64_t slot = kTrain ? unit / ka.chunks : unit;       // padded ray slot (workspace rows)
+        int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
         if (!ray_ok) local = a.n_rays - 1;
         {
@@ -433,13 +441,17 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
         asm volatile("" ::: "memory");            // the reads of the stash below stay below
         RayAccum racc;
         racc.reset();
-        for (int c = 0; c < ka.chunks; ++c) {
+        const int c_begin = kTrain ? (int)(unit - slot * ka.chunks) : 0;
+        const int c_end = kTrain ? c_begin + 1 : ka.chunks;
+        for (int c = c_begin; c < c_end; ++c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = s < S;
             const int sc = s < S - 1 ? s : S - 1;
+            const int64_t tile = slot * ka.chunks + c;        // chunk index in the workspace
+            const int64_t sp = tile * 16 + j;                 // padded sample index
             auto the_ray = [&]() {                // the wave's ray, back from LDS (broadcast reads)
-                // (a compiler barrier: otherwise the reads, and the 24 sine arguments of the direction that depend
-                //  only on them, are hoisted out of the chunk loop and then spilled across every layer)
+                // (a compiler barrier: otherwise the reads, and what depends only on them, are hoisted out of
+                //  the chunk loop and then spilled across every layer)
                 asm volatile("" ::: "memory");
                 Ray r;
                 const f32x4 r0 = *(const f32x4*)ray_stash;
@@ -447,42 +459,62 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 r.d[1] = ray_stash[4], r.d[2] = ray_stash[5];
                 return r;
             };
+            // training: lane-relative bases of this sample's saved rows (+ the tensor's offset)
+            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;
+            float* const stat = kTrain ? ws + sp : nullptr;
             f32x4 X[16], Y[16];                   // a layer's input tiles (B operands) / its accumulators, in turn
             {
                 const Ray ray = the_ray();
                 const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
                 const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
                 const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
-                if (g == 0) {
+                if (kTrain) {
+                    if (g == 0) *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{0.f, 0.f, dist, 0.f};
+                } else if (g == 0) {
                     *stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
                     *stash_dist = dist;
                 }
                 float pos_act[64];
-                encode_position(ray, t0, la, g, pos_act, kX);
+                encode_position(ray, t0, la, g, pos_act);
+                if (kTrain) {                     // both encodings as rows (un-scaled, as the fp32 forward saves them)
+                    float dir_act[64];
+                    encode_direction(ray, dlen, la, g, dir_act);
+                    float* prow = ws + ka.save.pos + sp * kEncPad + 4 * g;
+                    float* drow = ws + ka.save.dir + sp * kEncPad + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        *(f32x4*)(prow + 16 * t) = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]};
+                        *(f32x4*)(drow + 16 * t) = t < kDirTiles ? f32x4{dir_act[4 * t], dir_act[4 * t + 1], dir_act[4 * t + 2], dir_act[4 * t + 3]}
+                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < kPosTiles; ++t)
-                    X[t] = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]};
+                    X[t] = f32x4{pos_act[4 * t], pos_act[4 * t + 1], pos_act[4 * t + 2], pos_act[4 * t + 3]} * kX;
             }
             LazyNorm norm;
             HMoments mom;
             // ---- L0: X (encoded position, 2 k blocks) -> Y ----
             load_bias(small, g, Y);
-            nerf_fused::layer_fused_h<2, false, false, kOrderReluNorm>(pipe, X, Y, norm, mom);
-            norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(small), beta_of(small),
-                                                                                   g, nullptr, nullptr, kEps);
+            nerf_fused::layer_fused_h<2, false, kTrain, kOrderReluNorm>(pipe, X, Y, norm, mom);
+            norm = nerf_fused::finish_moments_at<kTrain, HMoments, kOrderReluNorm>(
+                mom, Y, gamma_of(small), beta_of(small), g, xrow + ka.save.xhat[0], stat + ka.save.rstd[0], kEps, kRs,
+                stat + ka.save.shift[0]);
             float dens = 0.f;
             // ---- L1 .. L9 in pairs (Y -> X, X -> Y): one code instance per direction ----
 #pragma unroll 1
             for (int p = 0; p < 5; ++p) {
-                const float* sa = small + (2 * p + 1) * kLegacySmallPerLayer;         // L1, L3, L5, L7, L9
+                const int la_ = 2 * p + 1;                                            // L1, L3, L5, L7, L9
+                const float* sa = small + la_ * kLegacySmallPerLayer;
                 load_bias(sa, g, X);
-                nerf_fused::layer_fused_h<8, true, false, kOrderReluNorm>(pipe, Y, X, norm, mom);
-                norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, X, gamma_of(sa), beta_of(sa), g,
-                                                                                       nullptr, nullptr, kEps);
+                nerf_fused::layer_fused_h<8, true, kTrain, kOrderReluNorm>(pipe, Y, X, norm, mom);
+                norm = nerf_fused::finish_moments_at<kTrain, HMoments, kOrderReluNorm>(
+                    mom, X, gamma_of(sa), beta_of(sa), g, xrow + ka.save.xhat[la_ < kWide ? la_ : 0],
+                    stat + ka.save.rstd[la_ < kWide ? la_ : 0], kEps, kRs, stat + ka.save.shift[la_ < kWide ? la_ : 0]);
                 if (p == 4) break;
                 const float* sb = sa + kLegacySmallPerLayer;                          // L2, L4, L6, L8
                 load_bias(sb, g, Y);
-                nerf_fused::layer_fused_h<8, true, false, kOrderReluNorm>(pipe, X, Y, norm, mom);
+                nerf_fused::layer_fused_h<8, true, kTrain, kOrderReluNorm>(pipe, X, Y, norm, mom);
                 if (p & 1) {
                     // L4: + [encoded position], L8: + [encoded direction]: two more k blocks, encoded here
                     h8 eh[2], el[2];
@@ -501,23 +533,30 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     for (int T = 0; T < 16; ++T) mom.template add<kOrderReluNorm>(Y[T]);
                     if (p == 3) {                 // density head on x'_7 (normalised in place by L8's fused loop)
                         const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-                        dens = head_layer_h<false>(pipe, hb[g], X, norm).x * kUn;
+                        dens = head_layer_h<false, kTrain>(pipe, hb[g], X, norm).x * kUn;
                     }
                 }
-                norm = nerf_fused::finish_moments_at<false, HMoments, kOrderReluNorm>(mom, Y, gamma_of(sb), beta_of(sb), g,
-                                                                                       nullptr, nullptr, kEps);
+                norm = nerf_fused::finish_moments_at<kTrain, HMoments, kOrderReluNorm>(
+                    mom, Y, gamma_of(sb), beta_of(sb), g, xrow + ka.save.xhat[la_ + 1], stat + ka.save.rstd[la_ + 1], kEps,
+                    kRs, stat + ka.save.shift[la_ + 1]);
             }
             const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-            const f32x4 col = head_layer_h<true>(pipe, hb[4 + g], X, norm) * kUn;
+            const f32x4 col = head_layer_h<true, kTrain>(pipe, hb[4 + g], X, norm) * kUn;
+            f32x4 out[4];
+            out[0] = f32x4{dens, col.x, col.y, col.z};
+            out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kTrain) {
+                float* otile = ws + ka.save.out + tile * 1024 + lane * 4;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) *(f32x4*)(otile + T * 256) = out[T];
+                continue;
+            }
             float dist;
             {
                 const f32x4 s0 = *stash;
                 racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
                 dist = *stash_dist;
             }
-            f32x4 out[4];
-            out[0] = f32x4{dens, col.x, col.y, col.z};
-            out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float w = composite_chunk<false, false>(a, S, local, s, ok, lane, out, dist, racc, nullptr);
             if (ray_ok && ok && g == 0) {
                 const int64_t smp = local * S + s;
@@ -530,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 }
             }
         }
-        store_ray<false>(a, local, ray_ok, lane, racc);
+        if (!kTrain) store_ray<false>(a, local, ray_ok, lane, racc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -550,7 +589,43 @@ __global__ void nerf_legacy_pack_kernel(const LegacyPackArgs pa) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kLegacyPackedFloats) return;
     float v = 0.f;
-    if (e >= kLegacyBwdOffset) {
+    if (e >= kLegacyBwdHOffset) {
+        // transposed f16-pair image of the data gradient (nerf_legacy_layout.h): two halfs of one slab per slot
+        const int eb = e - kLegacyBwdHOffset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        int sl;
+        const int L = bwd_h_layer_of_stage(stage, sl);
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k;
+            float w = 0.f;
+            if (L < 0) {
+                // a head: one k block (m = 0), half = sl; its outputs sit in k slots (kg 0, jj 0..3) as in the
+                // fp32 image: density at slot 0, color rows at slots 1..3
+                const int in = 16 * (8 * sl + pair) + row;
+                if (kg == 0 && jj < 4) {
+                    if (L == -2 && jj == 0) w = pa.p[kDensityW][in];
+                    if (L == -1 && jj >= 1) w = pa.p[kColorW][(jj - 1) * kHidden + in];
+                }
+            } else {
+                const int half = sl / 8, m = sl % 8;
+                const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
+                w = pa.p[wide_param(L)][out * wide_inputs(L) + 16 * (8 * half + pair) + row];
+            }
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
+    } else if (e >= kLegacyBwdOffset) {
         // transposed fp32 image of the data gradient (nerf_legacy_layout.h):
         // [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i], hidden columns only
         const int eb = e - kLegacyBwdOffset;
@@ -743,8 +818,7 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     const bool train = a.train_workspace != nullptr;
     if (train && a.out_raw != nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: out_raw is not produced by the training forward");
-    if (train && a.precision != NERF_HIP_PRECISION_FP32)
-        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "legacy_render_forward: the training forward of this network runs in fp32 arithmetic only");
+
     if (a.t_values == nullptr && a.t_table == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: t_table / t_values is null");
     if (!(args->normalize_position > 0.f))
@@ -765,21 +839,23 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_forward: unknown precision");
     const bool half = a.precision == NERF_HIP_PRECISION_F16X3;
-    static unsigned done = 0, done_h = 0, done_t = 0;
-    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_h_kernel, kLegacyLdsBytesHalf, device, &done_h)
-        : train ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<true>, kLegacyLdsBytes, device, &done_t)
-                : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_fwd_kernel<false>, kLegacyLdsBytes, device, &done);
+    typedef void (*Kernel)(const LegacyKernelArgs);
+    static const Kernel kernels[2][2] = {{nerf_legacy_fwd_kernel<false>, nerf_legacy_fwd_kernel<true>},
+                                         {nerf_legacy_fwd_h_kernel<false>, nerf_legacy_fwd_h_kernel<true>}};
+    static unsigned done[2][2] = {};
+    const Kernel kernel = kernels[half][train];
+    const int lds_bytes = half ? kLegacyLdsBytesHalf : kLegacyLdsBytes;
+    rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, &done[half][train]);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    if (half) hipLaunchKernelGGL(nerf_legacy_fwd_h_kernel, dim3((unsigned)grid), dim3(256), kLegacyLdsBytesHalf, st, ka);
-    else if (train) {
-        hipLaunchKernelGGL(nerf_legacy_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, ka);
+    if (train) {
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_legacy_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
-    } else hipLaunchKernelGGL(nerf_legacy_fwd_kernel<false>, dim3((unsigned)grid), dim3(256), kLegacyLdsBytes, st, ka);
+    }
     rc = nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
     nerf_common::Timing::after(st);
     return rc;

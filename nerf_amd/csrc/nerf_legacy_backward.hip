@@ -51,6 +51,8 @@ struct LBwdArgs {
     int64_t groups;
     LegacyTrainLayout L;
     float* gb_partial;          // [grid][10][2][256]
+    float* dymax;               // [grid][16]: largest |dY| each data-gradient workgroup saw: 0..9 dy[l], 10 the heads'
+                                // rows; split-precision path only
     float* slabs;               // [splits][kLSlabFloats]
     float* grad;
     int32_t splits, data_grid;
@@ -92,9 +94,12 @@ struct LegacyHook {
 //   in : acc = dL/dx' (the LayerNorm's output = the next Linear's input), saved a_hat tile, 1/std, shift
 //   out: act = dL/dy (the Linear's output) = the next B operands; also stored row-major
 //   d a = (gamma d x' - mean(gamma d x') - a_hat mean(gamma d x' a_hat)) / std ;  d y = d a where y > 0
+//   kScaled (split-precision chain): acc holds d x' times the per-sample power of two that `unscale` undoes
+template <bool kScaled = false>
 __device__ __forceinline__ void relu_layer_norm_bwd(const float* gamma_l, int g, int j, f32x4 (&acc)[16],
                                                     float (&act)[64], const f32x4 (&xh)[16], float rstd,
-                                                    float shift, float* dy_row, float* gb_l, GammaBetaTurn& turn) {
+                                                    float shift, float* dy_row, float* gb_l, GammaBetaTurn& turn,
+                                                    float unscale = 1.0f) {
     const f32x4* gam = (const f32x4*)(gamma_l + g * 64);
     float s1 = 0.f, s2 = 0.f;
     // one tile: gamma d x' into the accumulator, the two LayerNorm moments; v[0..3] = d x' (beta gradient
@@ -103,10 +108,11 @@ __device__ __forceinline__ void relu_layer_norm_bwd(const float* gamma_l, int g,
         const f32x4 ga = gam[T];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dz = acc[T][r];
-            // (the median of three copies: the value the inline-asm butterfly reads is then a VALU result, not
-            //  the raw accumulator of an MFMA that may still be in flight — nerf_amd/isa_scan.py rule R1)
-            v[r] = __builtin_amdgcn_fmed3f(dz, dz, dz);
+            // (the value the inline-asm butterfly reads must be a VALU result, not the raw accumulator of an MFMA
+            //  that may still be in flight — nerf_amd/isa_scan.py rule R1: the un-scaling product, or the median
+            //  of three copies)
+            const float dz = kScaled ? acc[T][r] * unscale : acc[T][r];
+            v[r] = kScaled ? dz : __builtin_amdgcn_fmed3f(dz, dz, dz);
             v[4 + r] = dz * xh[T][r];
             const float gdz = ga[r] * dz;
             s1 += gdz;
@@ -242,11 +248,139 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
         ba.gb_partial[(int64_t)blockIdx.x * kLGbFloats + i] = gb[i];
 }
 
+// The same chain in split-precision arithmetic (the training forward's precision = F16X3), as the main
+// network's nerf_bwd_data_h_kernel: a sample's dY row becomes f16 pairs after an exact per-sample power-of-two
+// scaling (row_scale), the transposed f16-pair image streams through the ring (layer_wide_h), the scale is
+// undone in the LayerNorm backward that consumes the accumulators.  The density head joins L8's product in the
+// SAME accumulators, so its single value takes part in that row's maximum and uses that row's scale.  The
+// largest |dY| of every layer is recorded per workgroup for the weight gradient's batch-wide scale.
+constexpr int kLYoungerHead = 18, kLYoungerHidden = 34;       // 16 a_hat + 1/std + shift loads (+ 16 dY saves)
+__global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LBwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* const ws = a.train_workspace;
+    float* const gamma = (float*)(smem + kRingBytes);
+    float* const gb = gamma + kGammaFloats;
+    int* const wmax = (int*)(smem + kLBwdLdsBytes);
+
+    for (int i = threadIdx.x; i < kGammaFloats; i += 256)
+        gamma[i] = a.packed[kLegacyBlobFloats + (i / kHidden) * kLegacySmallPerLayer + kHidden + (i % kHidden)];
+    for (int i = threadIdx.x; i < kLGbFloats; i += 256) gb[i] = 0.f;
+    if (threadIdx.x < 16) wmax[threadIdx.x] = 0;
+
+    WeightPipe<kLegacyBwdHStages> pipe;
+    pipe.init(a.packed + kLegacyBwdHOffset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;
+        const int64_t sp = tile * 16 + j;
+        const float* const xbase = ws + sp * kHidden + 4 * g;
+        float* const dybase = ws + sp * kHidden + 4 * g;
+        const float* const stat = ws + sp;
+        // dL/d(density, r, g, b) on lane group 0 (zeros elsewhere), then a_hat / 1/std / shift of L9: 18 loads
+        // that fly under the two stages of the color head
+        const f32x4 dh = *(const f32x4*)(ws + ba.L.dy5 + sp * kOutPad + 4 * g);
+        f32x4 xh[16];
+        float rstd, shift, unscale;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * 16);
+        rstd = stat[ba.L.rstd[9]];
+        shift = stat[ba.L.shift[9]];
+        {
+            float amax;
+            const float sc = row_scale(abs_max4(0.f, dh), unscale, amax);
+            note_max(wmax + 10, amax, lane);
+            h8 bh[1], bl[1];
+            split8(dh * sc, zero, bh[0], bl[0]);
+#pragma unroll
+            for (int T = 0; T < 16; ++T) acc[T] = zero;
+            layer_wide_h<1, kLYoungerHead>(pipe, acc, bh, bl);           // color head: dX'_9 = Wc^T d(color)
+        }
+        // L9, L8, [density head], L7 .. L1: ONE code instance of the layer body (two runs of the same loop)
+        int l = 9;
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            const int last = phase == 0 ? 8 : 1;
+            float sc = 1.0f, ddens = 0.f;
+#pragma unroll 1
+            for (; l >= last; --l) {
+                relu_layer_norm_bwd<true>(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
+                                          gb + l * 2 * kHidden, turn, unscale);
+                // the next LayerNorm backward's saved tile: 18 loads behind the 16 saves above (+ the density
+                // gradient, which joins L8's product in the same accumulators: same row, same scale)
+#pragma unroll
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + T * 16);
+                rstd = stat[ba.L.rstd[l - 1]];
+                shift = stat[ba.L.shift[l - 1]];
+                ddens = ws[ba.L.dy5 + sp * kOutPad];
+                // the sample's largest |dy|: this layer's B-operand scale, and (folded into the workgroup's
+                // maximum) the weight-gradient kernel's
+                float m = 0.f;
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    m = abs_max4(m, f32x4{act[4 * T], act[4 * T + 1], act[4 * T + 2], act[4 * T + 3]});
+                note_max(wmax + l, group_max(m), lane);
+                float amax;
+                sc = row_scale(l == 8 ? __builtin_fmaxf(m, __builtin_fabsf(ddens)) : m, unscale, amax);
+                h8 bh[8], bl[8];
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int t0 = 8 * mb, t1 = 8 * mb + 4;
+                    split8(f32x4{act[t0], act[t0 + 1], act[t0 + 2], act[t0 + 3]} * sc,
+                           f32x4{act[t1], act[t1 + 1], act[t1 + 2], act[t1 + 3]} * sc, bh[mb], bl[mb]);
+                }
+#pragma unroll
+                for (int T = 0; T < 16; ++T) acc[T] = zero;
+                layer_wide_h<8, kLYoungerHidden + 1>(pipe, acc, bh, bl, TurnHook{turn});
+            }
+            if (phase == 0) {                     // density head: dX'_7 += Wd^T d(density), under L8's row scale
+                h8 dbh[1], dbl[1];
+                split8(f32x4{g == 0 ? ddens * sc : 0.f, 0.f, 0.f, 0.f}, zero, dbh[0], dbl[0]);
+                layer_wide_h<1, 0>(pipe, acc, dbh, dbl);
+            }
+        }
+        relu_layer_norm_bwd<true>(gamma, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[0], gb, turn, unscale);
+        {
+            float m = 0.f;                        // dy[0] feeds only the weight gradient
+#pragma unroll
+            for (int T = 0; T < 16; ++T)
+                m = abs_max4(m, f32x4{act[4 * T], act[4 * T + 1], act[4 * T + 2], act[4 * T + 3]});
+            note_max(wmax, group_max(m), lane);
+        }
+        // layer 0's partials: the next item opens with the two-stage color head, so the four waves take their
+        // turns here, a barrier apart
+        for (int t = 0; t < kWavesPerWg; ++t) {
+            __syncthreads();
+            turn(t);
+        }
+        turn.kg = turn.kb = zero;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kLGbFloats + i] = gb[i];
+    if (threadIdx.x < 16) ba.dymax[(int64_t)blockIdx.x * 16 + threadIdx.x] = __builtin_bit_cast(float, wmax[threadIdx.x]);
+}
+
 // All 14 products in ONE launch: job = blockIdx.x / splits, heavy (256 x 256) blocks first.
 __global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_kernel(const LBwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
-    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kLSlabFloats, nullptr, 0};
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kLSlabFloats, nullptr, 0, 16};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kLegacyBlobFloats;            // [layer][bias | gamma | beta][256]
     if (job < kHiddenJobs) {
@@ -268,6 +402,36 @@ __global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_kernel(const LBwdArg
         wgrad_body_ring<ShapeL5, kInputAffine>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[l],
                                                small + l * kLegacySmallPerLayer, kLSlabHead + h * kOutPad * kHidden,
                                                kLSlabB + kWide * kHidden + h * kOutPad);
+    }
+}
+
+// The same launch in the split-precision training mode: every product on f16 pairs under ONE power-of-two
+// scale of its dY per batch (nerf_backward_common.h: wgrad_body_ring<.., kF16 = true>), taken from the maxima the
+// data-gradient kernel recorded (dymax index: the layer, 10 for the heads' rows).
+__global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_h_kernel(const LBwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kLSlabFloats, ba.dymax,
+                      ba.data_grid, 16};
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kLegacyBlobFloats;
+    if (job < kHiddenJobs) {
+        const int l = job + 1;
+        wgrad_body_ring<ShapeHid, kInputAffine, true>(jb, smem, ws + ba.L.dy[l], ws + ba.L.xhat[l - 1],
+                                                      small + (l - 1) * kLegacySmallPerLayer,
+                                                      kLSlabHid + job * kHidden * kHidden, kLSlabB + l * kHidden, l);
+    } else if (job < kHiddenJobs + 3) {
+        const int e = job - kHiddenJobs;
+        const int l = e == 0 ? 0 : (e == 1 ? 4 : 8);
+        wgrad_body_ring<ShapeEnc, kInputRaw, true>(jb, smem, ws + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
+                                                   kLSlabEnc + e * kHidden * kEncPad, e == 0 ? kLSlabB : kLSlabSpare, l);
+    } else {
+        const int h = job - kHiddenJobs - 3;
+        const int l = h == 0 ? 7 : 9;
+        wgrad_body_ring<ShapeL5, kInputAffine, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[l],
+                                                     small + l * kLegacySmallPerLayer,
+                                                     kLSlabHead + h * kOutPad * kHidden,
+                                                     kLSlabB + kWide * kHidden + h * kOutPad, 10);
     }
 }
 
@@ -342,7 +506,7 @@ extern "C" {
 
 size_t nerf_hip_legacy_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
     if (n_rays <= 0 || num_samples < 2) return 0;
-    return ((size_t)kMaxSplits * kLSlabFloats + (size_t)kMaxDataGrid * kLGbFloats) * sizeof(float);
+    return ((size_t)kMaxSplits * kLSlabFloats + (size_t)kMaxDataGrid * (kLGbFloats + 16)) * sizeof(float);
 }
 
 int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void* stream) {
@@ -358,8 +522,9 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: forward was not a training forward");
     if (a.n_rays < 0 || a.num_samples < 2 || a.num_samples > 4096)
         return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: n_rays / num_samples out of range");
-    if (a.precision != NERF_HIP_PRECISION_FP32)
-        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "legacy_render_backward: fp32 arithmetic only");
+    if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
+        return nerf_common::fail(NERF_HIP_EINVAL, "legacy_render_backward: unknown precision");
+    const bool half = a.precision == NERF_HIP_PRECISION_F16X3;          // the arithmetic of the training forward
     hipStream_t st = (hipStream_t)stream;
 
     LBwdArgs ba;
@@ -376,6 +541,7 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
     ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
     ba.slabs = args->scratch;
     ba.gb_partial = args->scratch + (size_t)kMaxSplits * kLSlabFloats;
+    ba.dymax = ba.gb_partial + (size_t)kMaxDataGrid * kLGbFloats;
 
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");
@@ -383,11 +549,15 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
     rc = nerf_common::check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device),
                                 "hipDeviceGetAttribute");
     if (rc) return rc;
-    static unsigned done_data = 0, done_wgrad = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_bwd_data_kernel, kLBwdLdsBytes, device, &done_data);
+    static unsigned done_data = 0, done_wgrad = 0, done_data_h = 0, done_wgrad_h = 0;
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_bwd_data_h_kernel, kLBwdLdsBytes + 64, device,
+                                                &done_data_h)
+              : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_bwd_data_kernel, kLBwdLdsBytes, device, &done_data);
     if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_wgrad_kernel, kRingSlots * kRingSlotBytes, device,
-                                         &done_wgrad);
+    rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_wgrad_h_kernel, kRingSlots * kRingSlotBytes,
+                                                device, &done_wgrad_h)
+              : nerf_common::ensure_dynamic_lds((const void*)nerf_legacy_wgrad_kernel, kRingSlots * kRingSlotBytes, device,
+                                                &done_wgrad);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
     if (grid > ba.groups) grid = ba.groups;
@@ -396,9 +566,15 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
 
     hipLaunchKernelGGL(nerf_legacy_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                        dim3(256), 0, st, ba);
-    hipLaunchKernelGGL(nerf_legacy_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes, st, ba);
-    hipLaunchKernelGGL(nerf_legacy_wgrad_kernel, dim3(ba.splits * kWgradJobs), dim3(256), kRingSlots * kRingSlotBytes,
-                       st, ba);
+    if (half) {
+        hipLaunchKernelGGL(nerf_legacy_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes + 64, st, ba);
+        hipLaunchKernelGGL(nerf_legacy_wgrad_h_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
+                           kRingSlots * kRingSlotBytes, st, ba);
+    } else {
+        hipLaunchKernelGGL(nerf_legacy_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes, st, ba);
+        hipLaunchKernelGGL(nerf_legacy_wgrad_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
+                           kRingSlots * kRingSlotBytes, st, ba);
+    }
     hipLaunchKernelGGL(nerf_legacy_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks),
                        dim3(kReduceThreads), 0, st, ba);
     return nerf_common::check_hip(hipGetLastError(), "legacy_render_backward launch");

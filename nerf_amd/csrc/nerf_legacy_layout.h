@@ -66,8 +66,24 @@ constexpr int kLegacyHSmallOffset = kLegacyHOffset + kLegacyHBlobFloats;
 constexpr int kLegacyBwdStages = 1 + 16 + 16 + 1 + 7 * 16;                      // 146
 constexpr int kLegacyBwdBlobFloats = kLegacyBwdStages * kStageFloats;
 constexpr int kLegacyBwdOffset = kLegacyHSmallOffset + kLegacySmallFloats;
-constexpr int kLegacyPackedFloats = kLegacyBwdOffset + kLegacyBwdBlobFloats;
 constexpr int kBwdColorStage = 0, kBwdDensityStage = 33;
+// ---- the same chain as f16 pairs (slab format: stage (half, m) = out tiles 8 half .. 8 half + 7 of k block m,
+// here "out" = the forward layer's IN features and k = its OUT features): a head is one k block (its 16 padded
+// outputs, zeros beyond) = 2 stages, a wide layer 8 k blocks = 16 stages
+//   stages 0..1 color head, 2..17 L9, 18..33 L8 (hidden columns), 34..35 density head, 36..147 L7 .. L1
+//   element (lane (row, kg), jj) of pair i = 2^kWScaleLog2 * W[k = 32 m + 16 (jj >> 2) + 4 kg + (jj & 3)][16 (8 half + i) + row]
+constexpr int kLegacyBwdHStages = 2 + 16 + 16 + 2 + 7 * 16;                    // 148
+constexpr int kLegacyBwdHBlobFloats = kLegacyBwdHStages * kStageFloats;
+constexpr int kLegacyBwdHOffset = kLegacyBwdOffset + kLegacyBwdBlobFloats;
+constexpr int kLegacyPackedFloats = kLegacyBwdHOffset + kLegacyBwdHBlobFloats;
+// wide layer of stage s of the f16 backward image (-1: color head, -2: density head); `local` = stage within it
+__host__ __device__ inline int bwd_h_layer_of_stage(int s, int& local) {
+    if (s < 2) { local = s; return -1; }
+    if (s < 34) { local = (s - 2) % 16; return 9 - (s - 2) / 16; }
+    if (s < 36) { local = s - 34; return -2; }
+    local = (s - 36) % 16;
+    return 7 - (s - 36) / 16;
+}
 // wide layer whose transposed weights stage s of the backward image carries (-1: a head stage)
 __host__ __device__ inline int bwd_layer_of_stage(int s, int& tout) {
     if (s == kBwdColorStage || s == kBwdDensityStage) { tout = 0; return -1; }

@@ -21,9 +21,11 @@ Training (the notebook's loop, cell 8: ``((pixels - batch['pixels']) ** 2).mean(
 with gradients enabled ``render_rays`` goes through ``LegacyRenderRaysFunction``, whose backward is
 ``nerf_hip_legacy_render_backward`` (nerf_amd/csrc/nerf_legacy_backward.hip): the 44 parameter gradients as
 views of ONE flat vector in ``parameters()`` order (``model.last_flat_grad``, what the data-parallel
-all-reduce runs on in place).  The training arithmetic is fp32 MFMA (forward, data gradient) and bf16
-triples (weight gradient), i.e. exact-fp32 products throughout; ``precision`` only selects the arithmetic of
-inference launches.
+all-reduce runs on in place).  ``train_precision`` selects the training arithmetic like
+``nerf_amd.model.NeRF.train_precision``: "fp32" = fp32 MFMA (forward, data gradient) and bf16 triples (weight
+gradient), exact-fp32 products throughout; "f16x3" = f16 pairs in all three (three f16 MFMAs per product, fp32
+accumulation, power-of-two scales of dY per sample / per batch), held to the same gradient tests.
+``precision`` selects the arithmetic of inference launches.
 """
 import ctypes
 import math
@@ -66,6 +68,7 @@ class LegacyRenderRaysFunction(torch.autograd.Function):
         ctx.call = (rays_o, rays_d, near, far, num_samples, u, noise, density_noise_std)
         ctx.workspace = workspace
         ctx.packed = model._last_packed               # the image this forward used (its own buffer)
+        ctx.precision = model.train_precision         # the backward runs in the forward's arithmetic
         ctx.shapes = [p.shape for p in params]
         ctx.save_for_backward(rgb)
         return rgb
@@ -81,7 +84,7 @@ class LegacyRenderRaysFunction(torch.autograd.Function):
         args = _lib.LegacyBackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, u=u,
                          noise=noise, density_noise_std=std, packed=ctx.packed, rgb=rgb,
-                         train_workspace=ctx.workspace, precision="fp32")
+                         train_workspace=ctx.workspace, precision=ctx.precision)
         grad = torch.empty(lib.nerf_hip_legacy_grad_elements(), dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_legacy_backward_scratch_bytes(n_rays, num_samples), device)
         args.d_rgb, args.grad, args.scratch = _lib.ptr(d_rgb), _lib.ptr(grad), _lib.ptr(scratch)
@@ -120,6 +123,8 @@ class LegacyNeRF8x256(nn.Module):
         # arithmetic of the twelve matrix products: "fp32" = exact-fp32 MFMA, "f16x3" = every operand
         # as an f16 pair, three f16 MFMAs per product, fp32 accumulation (as nerf_amd.model.NeRF.precision)
         self.precision = "fp32"
+        # arithmetic of launches that record a backward (forward, data gradient, weight gradient)
+        self.train_precision = "fp32"
 
     # pose helpers of the reference's class, unchanged (nerf/model.py:243-367)
     generate_rays = staticmethod(_GenerationC.generate_rays)
@@ -226,8 +231,10 @@ class LegacyNeRF8x256(nn.Module):
             weights = torch.empty(n_rays, num_samples, dtype=torch.float32, device=device)
         if self.precision not in _lib.PRECISIONS:
             raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
-        precision = "fp32" if train_workspace is not None else self.precision
-        if precision == "f16x3":
+        precision = self.train_precision if train_workspace is not None else self.precision
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        if precision == "f16x3" and not torch.cuda.is_current_stream_capturing():
             self._check_f16x3_range()
         args = _lib.LegacyArgs()
         self._fill_args(args, n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, cameras=cameras,

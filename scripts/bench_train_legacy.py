@@ -1,5 +1,5 @@
 """Timing of one training step (forward + backward + Adam) of the LEGACY 8 x 256 network on the GPU
-(the notebook's loop, examples/example.ipynb cell 8): python scripts/bench_train_legacy.py [rays] [samples]"""
+(the notebook's loop, examples/example.ipynb cell 8): python scripts/bench_train_legacy.py [rays] [samples] [fp32|f16x3]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE
@@ -8,6 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 torch.manual_seed(0)
 model = LegacyNeRF8x256().to(dev)
+model.train_precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 o = torch.randn(n, 3, device=dev) * 0.5; d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 def step():
@@ -22,5 +23,5 @@ K = 10
 for _ in range(K): l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"legacy train step {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l.detach()):.4f}")
+print(f"legacy train step [{model.train_precision}] {n} rays x {S}: {dt*1e3:.2f} ms/step, {n*S/dt:.3e} ray-samples/s, loss {float(l.detach()):.4f}")
 print(f"  algorithmic {3*FLOP_PER_SAMPLE*n*S/dt/1e12:.1f} TFLOP/s (fwd+dgrad+wgrad)")

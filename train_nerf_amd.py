@@ -72,8 +72,7 @@ if __name__ == "__main__":
                     density_noise_std=args.density_noise_std, log_interval=args.log_interval,
                     rng=args.rng, graph=args.graph, model=model, near=args.near_plane, far=args.far_plane)
     run.model.precision = args.precision
-    if args.network == "mipnerf":
-        run.model.train_precision = args.train_precision
+    run.model.train_precision = args.train_precision
     run.write_params(vars(args))
     run.fit(epochs=args.epochs, max_iterations=args.max_iterations)
     if run.rank == 0 and run.psnrs:
