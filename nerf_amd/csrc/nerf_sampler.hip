@@ -72,6 +72,7 @@ constexpr int kMaxPosts = 1024;
 // sorted lists done by rank: rank(fine k) = k + #coarse posts <= it, rank(coarse i) = i + #fine
 // samples < it, both read off the same monotone map u <-> t.
 __global__ __launch_bounds__(256) void nerf_resample_kernel(const NerfHipResampleArgs ra) {
+#pragma clang fp contract(off)                     // t0 + frac * (t1 - t0) as torch evaluates it: multiply, then add
     __shared__ float cdf_s[4][kMaxPosts];
     __shared__ float uf_s[4][kMaxPosts];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,22 +84,26 @@ __global__ __launch_bounds__(256) void nerf_resample_kernel(const NerfHipResampl
     float* cdf = cdf_s[wave];
     float* uf = uf_s[wave];
 
-    // inclusive scan of (w + floor) -> cdf[i + 1]
-    float carry = 0.f;
+    // inclusive scan of (w + floor) -> cdf[i + 1].  The spec (oracle/nerf_oracle.py: resample_fenceposts) is
+    // torch.cumsum on the CPU, which accumulates float32 input in DOUBLE and rounds every prefix to float: the
+    // scan runs in double too (the association differs from torch's sequential loop, but a double sum of <= 1023
+    // floats rounds to the same float except for one prefix in ~1e9) — the only fp64 arithmetic in the library,
+    // 7 adds per interval of a kernel that takes microseconds.
+    double carry = 0.0;
     for (int base = 0; base < P; base += 64) {
         const int i = base + lane;
-        float v = i < P ? w[i] + ra.pdf_floor : 0.f;
+        double v = i < P ? (double)(w[i] + ra.pdf_floor) : 0.0;       // w + floor: one fp32 add, as in the oracle
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const float up = __shfl_up(v, d);
+            const double up = __shfl_up(v, d);
             if (lane >= d) v += up;
         }
-        if (i < P) cdf[i + 1] = carry + v;
+        if (i < P) cdf[i + 1] = (float)(carry + v);
         carry += __shfl(v, 63);
     }
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_wave_barrier();
-    const float total = carry;
+    const float total = (float)carry;             // = cdf[P], the float the oracle divides by
     for (int i = lane; i <= P; i += 64) cdf[i] = i == P ? 1.0f : cdf[i] / total;
     for (int k = lane; k < Sf; k += 64)
         uf[k] = ra.u != nullptr ? ra.u[ray * Sf + k] : ((float)k + 0.5f) / (float)Sf;
