@@ -361,8 +361,13 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
     ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kSlabFloats);
 }
 
+// Split-K factor of the weight gradient: every split writes a partial slab of ALL gradients (1.2 MB; 2.7 MB for
+// the legacy network) that the reduce kernel reads back, so at small batches the slab traffic, not the GEMM, sets
+// the time (512 rays x 64 with 128 splits of 8 tiles: 156 MB written + read around 37 us of MFMA work).  24
+// 32-sample tiles per split keep one round of workgroups on the chip at that size (6 jobs x 42 splits = 252) and
+// leave the 4096-ray batch at the 128-split cap.
 int choose_splits(int64_t n_tiles) {
-    int64_t s = n_tiles / 8;
+    int64_t s = n_tiles / 24;
     if (s < 1) s = 1;
     if (s > kMaxSplits) s = kMaxSplits;
     return (int)s;
