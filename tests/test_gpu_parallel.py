@@ -121,3 +121,66 @@ def test_two_ranks_graph_replayed_training(tmp_path):
     assert g0["graph_rays"] == 100 and g1["graph_rays"] == 100
     assert torch.equal(g0["params"], g1["params"])
     assert g0["last"] == g0["last"] and g0["last"] < 0.5 * g0["first"]
+
+
+def _legacy_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import parallel, trainer as T
+        from nerf_amd.legacy import LegacyNeRF8x256
+        from oracle import legacy_oracle as L
+        dev = torch.device("cuda:0")
+        model = LegacyNeRF8x256()
+        model.load_state_dict(L.init_params(seed=4))
+        model = model.to(dev)
+        model.train_precision = "f16x3"
+        parallel.broadcast_parameters(model)
+        # an uneven split of one batch (61 + 35 rays), one in-place all-reduce of the flat 638,468-float gradient
+        torch.manual_seed(7)
+        o, d, tgt = torch.randn(96, 3) * 0.5, torch.randn(96, 3), torch.rand(96, 3)
+        u, noise = torch.rand(96, 24), torch.randn(96, 24)
+        lo, hi = (0, 61) if rank == 0 else (61, 96)
+        pix = model.render_rays(o[lo:hi].to(dev), d[lo:hi].to(dev), 2.0, 6.0, 24, randomly_sample=True,
+                                density_noise_std=1.0, u=u[lo:hi].to(dev), noise=noise[lo:hi].to(dev))
+        ((pix - tgt[lo:hi].to(dev)) ** 2).mean().backward()
+        reduce = parallel.FlatGradientAllReduce(model.parameters())
+        flat = reduce(model.last_flat_grad, (hi - lo) / 96)
+        assert reduce.in_place_calls == 1 and flat.data_ptr() == model.last_flat_grad.data_ptr()
+        # and the trainer: a few data-parallel steps of the notebook's recipe, replicas must stay identical
+        images, poses, focal = T.synthetic_scene(num_views=4, size=12, num_samples=24, device=dev)
+        run = T.Trainer(images, poses, focal, batch_size=128, learning_rate=5e-4, num_samples_per_ray=24,
+                        density_noise_std=0.5, log_interval=10 ** 9, seed=3, model=model, near=2.0, far=6.0)
+        last = float(run.fit(epochs=2))
+        params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        torch.save(dict(flat=flat.cpu(), params=params, last=last), os.path.join(out_dir, f"l{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_train_the_legacy_network(tmp_path):
+    """The data-parallel contract holds for the legacy 8 x 256 network too: the backward's flat gradient (in
+    parameters() order) is all-reduced in place, the weighted sum over uneven shards equals the single-process
+    gradient of the whole batch, and `Trainer` keeps two replicas bitwise identical."""
+    mp.spawn(_legacy_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    l0 = torch.load(os.path.join(tmp_path, "l0.pt"))
+    l1 = torch.load(os.path.join(tmp_path, "l1.pt"))
+    assert torch.equal(l0["flat"], l1["flat"]) and torch.equal(l0["params"], l1["params"])
+    assert l0["last"] == l0["last"]
+    from nerf_amd.legacy import LegacyNeRF8x256
+    from oracle import legacy_oracle as L
+    dev = torch.device("cuda:0")
+    model = LegacyNeRF8x256()
+    model.load_state_dict(L.init_params(seed=4))
+    model = model.to(dev)
+    model.train_precision = "f16x3"
+    torch.manual_seed(7)
+    o, d, tgt = torch.randn(96, 3) * 0.5, torch.randn(96, 3), torch.rand(96, 3)
+    u, noise = torch.rand(96, 24), torch.randn(96, 24)
+    pix = model.render_rays(o.to(dev), d.to(dev), 2.0, 6.0, 24, randomly_sample=True, density_noise_std=1.0,
+                            u=u.to(dev), noise=noise.to(dev))
+    ((pix - tgt.to(dev)) ** 2).mean().backward()
+    full = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+    assert full.numel() == 638468
+    assert (l0["flat"] - full).abs().max() <= 2e-6 * full.abs().max()
