@@ -183,4 +183,4 @@ def test_two_ranks_train_the_legacy_network(tmp_path):
     ((pix - tgt.to(dev)) ** 2).mean().backward()
     full = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
     assert full.numel() == 638468
-    assert (l0["flat"] - full).abs().max() <= 2e-6 * full.abs().max()
+    assert (l0["flat"] - full).abs().max() <= 1e-5 * full.abs().max()       # (f16-pair products: ~2^-22 each)
