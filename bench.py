@@ -161,10 +161,11 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
     backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
     from nerf_amd import NeRF
+    from nerf_amd.optim import Adam
     torch.manual_seed(0)
     model = NeRF().to(dev)
     model.train_precision = train_precision
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)      # as nerf_amd/trainer.py
+    opt = Adam(model.parameters(), lr=1e-4)                               # as nerf_amd/trainer.py
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)
 
@@ -199,10 +200,11 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
     HIP-graph replay (forward + loss + backward + fused Adam, draws from torch's graph-safe generator) —
     the path nerf_amd.trainer.Trainer(graph=True) takes; at this size launches, not kernels, set the pace."""
     from nerf_amd import NeRF
+    from nerf_amd.optim import Adam
     torch.manual_seed(0)
     model = NeRF().to(dev)
     model.train_precision = train_precision
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+    opt = Adam(model.parameters(), lr=1e-4)
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)
 
@@ -373,10 +375,11 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, trai
     (44 gradients) + fused Adam, 4096 rays x 64 samples, stratified draws, noise std 1.  fp32 MFMA forward and
     data gradient, bf16-triple weight gradient (exact-fp32 products throughout).  Parity unpinned."""
     from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE as LEGACY_FLOP
+    from nerf_amd.optim import Adam
     torch.manual_seed(0)
     model = LegacyNeRF8x256().to(dev)
     model.train_precision = train_precision
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    opt = Adam(model.parameters(), lr=1e-4)
     o = torch.randn(rays, 3, device=dev) * 0.5
     d = torch.randn(rays, 3, device=dev)
     target = torch.rand(rays, 3, device=dev)

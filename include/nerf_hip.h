@@ -244,6 +244,26 @@ typedef struct NerfHipLegacyBackwardArgs {
 size_t nerf_hip_legacy_backward_scratch_bytes(int64_t n_rays, int32_t num_samples);
 int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void* stream);
 
+/* The optimiser step of the reference's training loops — torch.optim.Adam(parameters, lr) with its default
+ * betas / eps, no weight decay, no amsgrad (train_conditional_nerf.py:106-107, :135; examples/example.ipynb
+ * cells 7, 8) — as ONE launch over all parameter tensors (22 or 44 here; torch's fused kernel spends 43 us on
+ * them).  State (exp_avg, exp_avg_sq) is flat, in the order of the tensor list; `step` is a DEVICE float holding
+ * the step count t of this update (the caller increments it first), so a captured launch replays correctly. */
+#define NERF_HIP_ADAM_MAX_TENSORS 64
+typedef struct NerfHipAdamArgs {
+    int32_t num_tensors;
+    int64_t total;                                      /* parameters in all                         */
+    int64_t offsets[NERF_HIP_ADAM_MAX_TENSORS + 1];     /* prefix sums of the tensor sizes, [0] = 0  */
+    float* params[NERF_HIP_ADAM_MAX_TENSORS];           /* updated in place                          */
+    const float* grads[NERF_HIP_ADAM_MAX_TENSORS];      /* one per tensor (views of a flat gradient or not) */
+    float* exp_avg;                                     /* [total] first moment                      */
+    float* exp_avg_sq;                                  /* [total] second moment                     */
+    const float* step;                                  /* [1] device: t >= 1                        */
+    float lr, beta1, beta2, eps;
+} NerfHipAdamArgs;
+
+int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream);
+
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
  * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */

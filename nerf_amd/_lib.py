@@ -72,6 +72,18 @@ class LegacyBackwardArgs(ctypes.Structure):
     _fields_ = [("fwd", LegacyArgs), ("d_rgb", _f32p), ("grad", _f32p), ("scratch", _f32p)]
 
 
+ADAM_MAX_TENSORS = 64
+
+
+class AdamArgs(ctypes.Structure):
+    """Mirror of NerfHipAdamArgs (include/nerf_hip.h)."""
+    _fields_ = [("num_tensors", ctypes.c_int32), ("total", ctypes.c_int64),
+                ("offsets", ctypes.c_int64 * (ADAM_MAX_TENSORS + 1)),
+                ("params", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grads", ctypes.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", _f32p), ("exp_avg_sq", _f32p), ("step", _f32p),
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 NUM_LEGACY_PARAM_TENSORS = 44
 _lib = None
 
@@ -119,6 +131,8 @@ def lib():
     handle.nerf_hip_legacy_backward_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
     handle.nerf_hip_legacy_render_backward.restype = ctypes.c_int
     handle.nerf_hip_legacy_render_backward.argtypes = [ctypes.POINTER(LegacyBackwardArgs), ctypes.c_void_p]
+    handle.nerf_hip_adam_step.restype = ctypes.c_int
+    handle.nerf_hip_adam_step.argtypes = [ctypes.POINTER(AdamArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -143,7 +157,8 @@ EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "n
            "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_legacy_packed_bytes",
            "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward",
            "nerf_hip_legacy_train_workspace_bytes", "nerf_hip_legacy_grad_elements",
-           "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_timing",
+           "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_adam_step",
+           "nerf_hip_timing",
            "nerf_hip_timing_read")
 
 

@@ -119,9 +119,6 @@ class Trainer:
         self.draws = torch.Generator(device=device).manual_seed(seed + 7919 * (self.rank + 1))
         if self.distributed:
             parallel.broadcast_parameters(self.model)
-        # the reference's optimiser (train_conditional_nerf.py:106); on the GPU in its single-kernel
-        # ("fused") form: the default multi-tensor form is seven launches over the 22 tensors, 0.11 ms of
-        # a 0.8 ms step at 512 rays per GPU
         # graph: replay forward + loss + backward (+ the optimiser step when single-process) as ONE HIP
         # graph per iteration.  At 512 rays per GPU (BASELINE config 5 on 8 GPUs) a step is launch-bound:
         # ~27 kernel launches and the autograd hop cost more than the 0.33 ms the kernels run
@@ -139,8 +136,14 @@ class Trainer:
                 raise ValueError("graph=True needs rng='torch': the in-kernel Philox offset is a launch "
                                  "argument, a replayed launch would repeat its draws")
             torch.cuda.manual_seed(seed + 7919 * (self.rank + 1))      # draws come from the default generator
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate, fused=on_gpu,
-                                          capturable=self.use_graph and not self.distributed)
+        # the reference's optimiser (train_conditional_nerf.py:106-107: Adam, default betas / eps) as one launch
+        # over all parameter tensors (nerf_amd/optim.py; graph-capturable by construction: its step count lives on
+        # the device); torch's own on the CPU
+        if on_gpu:
+            from .optim import Adam
+            self.optimizer = Adam(self.model.parameters(), lr=learning_rate)
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=learning_rate)
         self.reduce = parallel.FlatGradientAllReduce(self.model.parameters())
         self.batch_size = batch_size
         self.num_samples = num_samples_per_ray

@@ -2,12 +2,13 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF, _lib
+from nerf_amd.optim import Adam
 dev = torch.device('cuda:0')
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
 torch.manual_seed(0)
 model = NeRF().to(dev)
 model.train_precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)      # as nerf_amd/trainer.py
+opt = Adam(model.parameters(), lr=1e-4)                               # as nerf_amd/trainer.py
 o = torch.randn(n, 3, device=dev); d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 def step():
     rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0)

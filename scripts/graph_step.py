@@ -3,13 +3,14 @@ usage: python scripts/graph_step.py [rays] [fp32|f16x3]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF
+from nerf_amd.optim import Adam
 dev = torch.device("cuda:0")
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 64
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
 torch.manual_seed(0)
 model = NeRF().to(dev)
 model.train_precision = prec
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+opt = Adam(model.parameters(), lr=1e-4)
 o = torch.randn(n, 3, device=dev); d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 u = torch.rand(n, S, device=dev); noise = torch.randn(n, S - 1, 1, device=dev)
 
