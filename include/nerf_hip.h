@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 4
+#define NERF_HIP_ABI_VERSION 5
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -247,8 +247,10 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
 /* The optimiser step of the reference's training loops — torch.optim.Adam(parameters, lr) with its default
  * betas / eps, no weight decay, no amsgrad (train_conditional_nerf.py:106-107, :135; examples/example.ipynb
  * cells 7, 8) — as ONE launch over all parameter tensors (22 or 44 here; torch's fused kernel spends 43 us on
- * them).  State (exp_avg, exp_avg_sq) is flat, in the order of the tensor list; `step` is a DEVICE float holding
- * the step count t of this update (the caller increments it first), so a captured launch replays correctly. */
+ * them).  State (exp_avg, exp_avg_sq) is flat, in the order of the tensor list.  `step` is a DEVICE float: the
+ * number of updates applied so far; the launch applies update number step + 1 and stores that count back when
+ * its last workgroup retires (`done`: a zero-initialised device counter the kernel leaves at zero), so a
+ * captured launch replays correctly and the count costs no launch of its own. */
 #define NERF_HIP_ADAM_MAX_TENSORS 64
 typedef struct NerfHipAdamArgs {
     int32_t num_tensors;
@@ -258,11 +260,28 @@ typedef struct NerfHipAdamArgs {
     const float* grads[NERF_HIP_ADAM_MAX_TENSORS];      /* one per tensor (views of a flat gradient or not) */
     float* exp_avg;                                     /* [total] first moment                      */
     float* exp_avg_sq;                                  /* [total] second moment                     */
-    const float* step;                                  /* [1] device: t >= 1                        */
+    float* step;                                        /* [1] device: updates applied so far (read, then + 1) */
+    uint32_t* done;                                     /* [1] device: 0 between launches            */
     float lr, beta1, beta2, eps;
 } NerfHipAdamArgs;
 
 int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream);
+
+/* The loss of those loops and its gradient in one launch: loss = mean((pred - target[:, None, :]) ** 2) over
+ * pred [n_rays, stages, 3] and target [n_rays, 3] (train_conditional_nerf.py:132: `((pixels -
+ * batch["pixels"].unsqueeze(1)) ** 2).mean()`; examples/example.ipynb cell 8), grad = d loss / d pred =
+ * (1 / count) * 2 (pred - target), rounded as autograd rounds it.  n_rays == 0 gives loss 0 (an empty shard of a
+ * data-parallel batch), not NaN.  One workgroup, a fixed summation order: the loss is reproducible. */
+typedef struct NerfHipMseArgs {
+    const float* pred;          /* [n_rays, stages, 3] */
+    const float* target;        /* [n_rays, 3]         */
+    int64_t n_rays;
+    int32_t stages;
+    float* loss;                /* [1]                 */
+    float* grad;                /* [n_rays, stages, 3] */
+} NerfHipMseArgs;
+
+int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream);
 
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing

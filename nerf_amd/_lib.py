@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -80,8 +80,14 @@ class AdamArgs(ctypes.Structure):
     _fields_ = [("num_tensors", ctypes.c_int32), ("total", ctypes.c_int64),
                 ("offsets", ctypes.c_int64 * (ADAM_MAX_TENSORS + 1)),
                 ("params", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grads", ctypes.c_void_p * ADAM_MAX_TENSORS),
-                ("exp_avg", _f32p), ("exp_avg_sq", _f32p), ("step", _f32p),
+                ("exp_avg", _f32p), ("exp_avg_sq", _f32p), ("step", _f32p), ("done", ctypes.c_void_p),
                 ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
+class MseArgs(ctypes.Structure):
+    """Mirror of NerfHipMseArgs (include/nerf_hip.h)."""
+    _fields_ = [("pred", _f32p), ("target", _f32p), ("n_rays", ctypes.c_int64), ("stages", ctypes.c_int32),
+                ("loss", _f32p), ("grad", _f32p)]
 
 
 NUM_LEGACY_PARAM_TENSORS = 44
@@ -133,6 +139,8 @@ def lib():
     handle.nerf_hip_legacy_render_backward.argtypes = [ctypes.POINTER(LegacyBackwardArgs), ctypes.c_void_p]
     handle.nerf_hip_adam_step.restype = ctypes.c_int
     handle.nerf_hip_adam_step.argtypes = [ctypes.POINTER(AdamArgs), ctypes.c_void_p]
+    handle.nerf_hip_mse_loss.restype = ctypes.c_int
+    handle.nerf_hip_mse_loss.argtypes = [ctypes.POINTER(MseArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
     handle.nerf_hip_timing.argtypes = [ctypes.c_int]
     handle.nerf_hip_timing_read.restype = ctypes.c_int
@@ -157,7 +165,7 @@ EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "n
            "nerf_hip_gather_pixel_rays", "nerf_hip_resample_pdf", "nerf_hip_legacy_packed_bytes",
            "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward",
            "nerf_hip_legacy_train_workspace_bytes", "nerf_hip_legacy_grad_elements",
-           "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_adam_step",
+           "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_adam_step", "nerf_hip_mse_loss",
            "nerf_hip_timing",
            "nerf_hip_timing_read")
 

@@ -158,8 +158,8 @@ extern "C" int nerf_hip_resample_pdf(const NerfHipResampleArgs* args, void* stre
 // model (22 or 44 tensors, 0.3-0.6 M parameters) that is ~20 workgroups and 43 us of a 0.4 ms training step
 // at 512 rays per GPU; here one thread owns one parameter (1,190 workgroups, a few microseconds).
 //   m <- b1 m + (1 - b1) g ;  v <- b2 v + (1 - b2) g^2 ;  p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-// t comes from DEVICE memory (`step[0]`, already incremented by the caller), so a captured launch replays
-// correctly.
+// t = step[0] + 1 with step[0] in DEVICE memory, so a captured launch replays correctly; the workgroup that
+// retires last (a device counter) stores t back: every workgroup has read the old count by then.
 namespace {
 
 struct AdamKernelArgs {
@@ -170,22 +170,56 @@ __global__ void nerf_adam_kernel(const AdamKernelArgs ka) {
 #pragma clang fp contract(off)
     const NerfHipAdamArgs& a = ka.a;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.total) return;
-    int lo = 0, hi = a.num_tensors;               // tensor t with offsets[t] <= e < offsets[t + 1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= e) lo = mid; else hi = mid;
+    const float t = a.step[0] + 1.0f;
+    if (e < a.total) {
+        int lo = 0, hi = a.num_tensors;               // tensor t with offsets[t] <= e < offsets[t + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.offsets[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int64_t i = e - a.offsets[lo];
+        const float g = a.grads[lo][i];
+        const float bc1 = 1.0f - powf(a.beta1, t), bc2 = 1.0f - powf(a.beta2, t);
+        const float m = a.beta1 * a.exp_avg[e] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.exp_avg_sq[e] + (1.0f - a.beta2) * (g * g);
+        a.exp_avg[e] = m;
+        a.exp_avg_sq[e] = v;
+        const float denom = __builtin_sqrtf(v) / __builtin_sqrtf(bc2) + a.eps;
+        a.params[lo][i] = a.params[lo][i] - (a.lr / bc1) * (m / denom);
     }
-    const int64_t i = e - a.offsets[lo];
-    const float g = a.grads[lo][i];
-    const float t = a.step[0];
-    const float bc1 = 1.0f - powf(a.beta1, t), bc2 = 1.0f - powf(a.beta2, t);
-    const float m = a.beta1 * a.exp_avg[e] + (1.0f - a.beta1) * g;
-    const float v = a.beta2 * a.exp_avg_sq[e] + (1.0f - a.beta2) * (g * g);
-    a.exp_avg[e] = m;
-    a.exp_avg_sq[e] = v;
-    const float denom = __builtin_sqrtf(v) / __builtin_sqrtf(bc2) + a.eps;
-    a.params[lo][i] = a.params[lo][i] - (a.lr / bc1) * (m / denom);
+    __syncthreads();                                  // every thread of this workgroup holds t
+    if (threadIdx.x == 0 && atomicAdd(a.done, 1u) == gridDim.x - 1) {
+        a.step[0] = t;
+        *a.done = 0u;
+    }
+}
+
+// mean((pred - target)^2) and its gradient: one workgroup of 1,024 threads, strided partial sums, a fixed tree.
+struct MseKernelArgs {
+    NerfHipMseArgs a;
+};
+
+__global__ __launch_bounds__(1024) void nerf_mse_kernel(const MseKernelArgs ka) {
+#pragma clang fp contract(off)
+    __shared__ float part[1024];
+    const NerfHipMseArgs& a = ka.a;
+    const int64_t per_ray = (int64_t)a.stages * 3, count = a.n_rays * per_ray;
+    const float inv = 1.0f / (float)(count > 0 ? count : 1);      // autograd: d loss / d sum = 1 / count ...
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < count; e += 1024) {
+        const int64_t ray = e / per_ray;
+        const int c = (int)(e - ray * per_ray) % 3;
+        const float x = a.pred[e] - a.target[ray * 3 + c];
+        acc += x * x;
+        a.grad[e] = inv * (2.0f * x);                              // ... times d x^2 / d x = 2 x, one rounding
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss[0] = part[0] / (float)(count > 0 ? count : 1);
 }
 
 }  // namespace
@@ -194,7 +228,7 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: null args");
     const NerfHipAdamArgs& a = *args;
     if (a.num_tensors < 1 || a.num_tensors > NERF_HIP_ADAM_MAX_TENSORS || a.total < 0 || a.step == nullptr ||
-        a.exp_avg == nullptr || a.exp_avg_sq == nullptr)
+        a.done == nullptr || a.exp_avg == nullptr || a.exp_avg_sq == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: tensor count / state pointers out of range");
     if (a.offsets[0] != 0 || a.offsets[a.num_tensors] != a.total)
         return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: offsets must run from 0 to total");
@@ -208,4 +242,17 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     const int64_t blocks = (a.total + threads - 1) / threads;
     hipLaunchKernelGGL(nerf_adam_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, ka);
     return nerf_common::check_hip(hipGetLastError(), "adam_step launch");
+}
+
+extern "C" int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream) {
+    if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null args");
+    const NerfHipMseArgs& a = *args;
+    if (a.n_rays < 0 || a.stages < 1 || a.loss == nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: n_rays / stages / loss pointer out of range");
+    if (a.n_rays > 0 && (a.pred == nullptr || a.target == nullptr || a.grad == nullptr))
+        return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null tensor");
+    MseKernelArgs ka;
+    ka.a = a;
+    hipLaunchKernelGGL(nerf_mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ka);
+    return nerf_common::check_hip(hipGetLastError(), "mse_loss launch");
 }

@@ -4,8 +4,8 @@ The reference's training loops build ``optim.Adam(nerf.parameters(), lr=...)`` w
 weight decay and no amsgrad (train_conditional_nerf.py:106-107, examples/example.ipynb cell 7).  This class is that
 optimiser for parameters on a ROCm device: same constructor arguments (the unsupported options raise), same
 update rule, ``torch.optim.Optimizer`` protocol (``zero_grad``, ``param_groups``, ``state_dict`` with the flat
-moments), and graph-capturable by construction: the step count lives on the device and every step is one add and
-one kernel launch.  torch's fused multi-tensor kernel needs 43 us for this model's 22 small tensors; at 512
+moments), and graph-capturable by construction: the step count lives on the device, the kernel itself increments
+it, and every step is ONE kernel launch.  torch's fused multi-tensor kernel needs 43 us for this model's 22 small tensors; at 512
 rays per GPU (BASELINE config 5 on 8 GPUs) that is a tenth of the training step.
 """
 import ctypes
@@ -27,6 +27,7 @@ class Adam(torch.optim.Optimizer):
         if not 1 <= len(self._params) <= _lib.ADAM_MAX_TENSORS:
             raise ValueError(f"nerf_amd.optim.Adam takes 1 .. {_lib.ADAM_MAX_TENSORS} parameter tensors")
         self._flat = None
+        self._done = None
 
     def _state(self):
         if self._flat is None:
@@ -39,6 +40,7 @@ class Adam(torch.optim.Optimizer):
             self._flat = dict(exp_avg=torch.zeros(total, dtype=torch.float32, device=dev),
                               exp_avg_sq=torch.zeros(total, dtype=torch.float32, device=dev),
                               step=torch.zeros(1, dtype=torch.float32, device=dev))
+            self._done = torch.zeros(1, dtype=torch.int32, device=dev)      # the kernel's retirement counter
             self.state["flat"] = self._flat          # (visible through state_dict())
         return self._flat
 
@@ -65,8 +67,8 @@ class Adam(torch.optim.Optimizer):
         args.offsets[len(self._params)] = off
         args.total = off
         args.exp_avg, args.exp_avg_sq, args.step = _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(st["step"])
+        args.done = self._done.data_ptr()             # (the step count is read AND incremented on the device)
         args.lr, (args.beta1, args.beta2), args.eps = float(group["lr"]), group["betas"], float(group["eps"])
-        st["step"].add_(1.0)                          # on the device: a replayed step counts too
         dev = self._params[0].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream

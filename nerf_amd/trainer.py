@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .dataset import PixelRayDataset
+from .loss import mse
 from .model import NeRF
 from . import parallel
 
@@ -179,7 +180,16 @@ class Trainer:
                                           u=u, noise=noise)
         pixels, _ = self.model.render_rays(rays_o, rays_d, self.num_samples, randomly_sample=True,
                                            density_noise_std=self.density_noise_std, u=u, noise=noise)
-        return pixels[:, 0]                               # the single stage (train_conditional_nerf.py:132)
+        return pixels.view(-1, 3)                         # the single stage (train_conditional_nerf.py:132); a view:
+                                                          # its backward launches nothing (a select would: zeros + copy)
+
+    @staticmethod
+    def _loss(pixels, target):
+        """The loop's MSE (train_conditional_nerf.py:132).  On the GPU: loss and gradient in one launch
+        (nerf_amd.loss.mse); an empty shard (tail of an epoch) gives 0, not NaN, either way."""
+        if pixels.is_cuda:
+            return mse(pixels, target)
+        return ((pixels - target) ** 2).sum() / max(pixels.numel(), 1)
 
     # ---- HIP-graph path ---------------------------------------------------------------------------
     def _graph_body(self, o, d, pix):
@@ -187,7 +197,7 @@ class Trainer:
         u, noise = self._draw(n, dev, None)               # graph-safe default generator
         self.last_draws = (u, noise)                      # (static tensors of the graph once captured)
         pixels = self._render(o, d, u, noise)
-        loss = ((pixels - pix) ** 2).sum() / max(3 * n, 1)
+        loss = self._loss(pixels, pix)
         loss.backward()
         if not self.distributed:
             self.optimizer.step()
@@ -258,8 +268,7 @@ class Trainer:
         self.last_draws = (u, noise)                      # what this step rendered with (None: in-kernel Philox)
         pixels = self._render(batch["rays_o"], batch["rays_d"], u, noise)
         self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
-        # sum / count instead of mean(): an empty shard (tail of an epoch) gives 0, not NaN
-        loss = ((pixels - batch["pixels"]) ** 2).sum() / max(3 * n, 1)
+        loss = self._loss(pixels, batch["pixels"])
         loss.backward()
         if self.distributed:
             self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))

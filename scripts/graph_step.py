@@ -4,6 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF
 from nerf_amd.optim import Adam
+from nerf_amd.loss import mse
 dev = torch.device("cuda:0")
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 64
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
@@ -16,7 +17,7 @@ u = torch.rand(n, S, device=dev); noise = torch.randn(n, S - 1, 1, device=dev)
 
 def step():
     rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0, u=u, noise=noise)
-    loss = ((rgb - tgt.unsqueeze(1)) ** 2).mean()
+    loss = mse(rgb, tgt)
     loss.backward()
     opt.step()
     return loss

@@ -1,7 +1,8 @@
 """nerf_amd.optim.Adam (one HIP launch over all parameter tensors) against torch.optim.Adam — the optimiser the
 reference's loops construct (train_conditional_nerf.py:106-107, :135; examples/example.ipynb cells 7, 8): same
-trajectory over many steps on both networks' parameter sets, under HIP-graph replay, and the options it does not
-implement are refused."""
+trajectory over many steps on both networks' parameter sets, under HIP-graph replay (the kernel itself counts the
+steps), and the options it does not implement are refused.  Also here: nerf_amd.loss.mse, the loops' loss and its
+gradient in one launch."""
 import pytest
 import torch
 
@@ -78,3 +79,38 @@ def test_unsupported_options_are_refused():
     opt = Adam([w])
     with pytest.raises(RuntimeError):
         opt.step()                                  # no gradient
+
+
+@pytest.mark.parametrize("shape", [(512, 1, 3), (4096, 1, 3), (64, 2, 3), (1000, 3), (1, 1, 3)])
+def test_fused_mse_is_the_loops_loss_and_autograds_gradient(shape):
+    """nerf_amd.loss.mse against the reference's expression (train_conditional_nerf.py:132) through autograd: the
+    loss to summation-order rounding, the gradient BIT FOR BIT ((1 / count) * (2 x), one rounding each)."""
+    from nerf_amd.loss import mse
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pred = torch.rand(shape, device=dev, generator=gen).requires_grad_(True)
+    target = torch.rand(shape[0], 3, device=dev, generator=gen)
+    ref_pred = pred.detach().clone().requires_grad_(True)
+    want = ((ref_pred - (target.unsqueeze(1) if len(shape) == 3 else target)) ** 2).mean()
+    want.backward()
+    got = mse(pred, target)
+    got.backward()
+    assert got.shape == () and abs(float(got) - float(want)) <= 2e-6 * float(want)
+    assert torch.equal(pred.grad, ref_pred.grad)
+    # an upstream factor (a weighted sum of losses) scales the gradient like autograd does
+    pred.grad = None
+    (3.0 * mse(pred, target)).backward()
+    assert torch.allclose(pred.grad, 3.0 * ref_pred.grad, rtol=1e-6, atol=0.0)
+    # reproducible: one workgroup, a fixed summation order
+    assert float(mse(pred, target)) == float(got)
+
+
+def test_fused_mse_of_an_empty_shard_is_zero():
+    from nerf_amd.loss import mse
+    dev = torch.device("cuda:0")
+    pred = torch.zeros(0, 1, 3, device=dev, requires_grad=True)
+    loss = mse(pred, torch.zeros(0, 3, device=dev))
+    loss.backward()
+    assert float(loss) == 0.0 and pred.grad.shape == (0, 1, 3)
+    with pytest.raises(ValueError):
+        mse(torch.zeros(4, 2, device=dev), torch.zeros(4, 3, device=dev))
