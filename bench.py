@@ -162,7 +162,7 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
     backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
     from nerf_amd import NeRF
     from nerf_amd.optim import Adam
-    from nerf_amd.loss import mse
+    from nerf_amd.loss import mse_and_grad
     torch.manual_seed(0)
     model = NeRF().to(dev)
     model.train_precision = train_precision
@@ -172,9 +172,9 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
 
     def step():
         pixels, _ = model.render_rays(o, d, samples, randomly_sample=True, density_noise_std=1.0)
-        loss = mse(pixels, target)
+        loss, grad = mse_and_grad(pixels, target)        # the Trainer's step: loss + gradient in one launch
         opt.zero_grad()
-        loss.backward()
+        pixels.backward(grad)
         opt.step()
 
     for _ in range(warmup):
@@ -202,7 +202,7 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
     the path nerf_amd.trainer.Trainer(graph=True) takes; at this size launches, not kernels, set the pace."""
     from nerf_amd import NeRF
     from nerf_amd.optim import Adam
-    from nerf_amd.loss import mse
+    from nerf_amd.loss import mse_and_grad
     torch.manual_seed(0)
     model = NeRF().to(dev)
     model.train_precision = train_precision
@@ -214,8 +214,8 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
         u = torch.rand(rays, samples, device=dev)
         noise = torch.randn(rays, samples - 1, 1, device=dev)
         pixels, _ = model.render_rays(o, d, samples, randomly_sample=True, density_noise_std=1.0, u=u, noise=noise)
-        loss = mse(pixels, target)
-        loss.backward()
+        loss, grad = mse_and_grad(pixels, target)
+        pixels.backward(grad)
         opt.step()
 
     def timed(fn):
@@ -378,7 +378,7 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, trai
     data gradient, bf16-triple weight gradient (exact-fp32 products throughout).  Parity unpinned."""
     from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE as LEGACY_FLOP
     from nerf_amd.optim import Adam
-    from nerf_amd.loss import mse
+    from nerf_amd.loss import mse_and_grad
     torch.manual_seed(0)
     model = LegacyNeRF8x256().to(dev)
     model.train_precision = train_precision
@@ -389,9 +389,9 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, trai
 
     def step():
         pixels = model.render_rays(o, d, 2.0, 6.0, samples, randomly_sample=True, density_noise_std=1.0)
-        loss = mse(pixels, target)
+        loss, grad = mse_and_grad(pixels, target)        # the Trainer's step: loss + gradient in one launch
         opt.zero_grad()
-        loss.backward()
+        pixels.backward(grad)
         opt.step()
 
     for _ in range(warmup):

@@ -247,11 +247,13 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
 /* The optimiser step of the reference's training loops — torch.optim.Adam(parameters, lr) with its default
  * betas / eps, no weight decay, no amsgrad (train_conditional_nerf.py:106-107, :135; examples/example.ipynb
  * cells 7, 8) — as ONE launch over all parameter tensors (22 or 44 here; torch's fused kernel spends 43 us on
- * them).  State (exp_avg, exp_avg_sq) is flat, in the order of the tensor list.  `step` is a DEVICE float: the
- * number of updates applied so far; the launch applies update number step + 1 and stores that count back when
- * its last workgroup retires (`done`: a zero-initialised device counter the kernel leaves at zero), so a
- * captured launch replays correctly and the count costs no launch of its own. */
+ * them).  State (exp_avg, exp_avg_sq) is flat, in the order of the tensor list.  `step` holds the number of
+ * updates applied so far in DEVICE memory, one copy per workgroup of the launch (NERF_HIP_ADAM_STEP_SLOTS equal
+ * floats, zero-initialised): workgroup b applies update number step[b] + 1 and stores that count back into its
+ * own slot, so no workgroup reads a count another one has already advanced, a captured launch replays
+ * correctly, and counting costs neither a launch nor an atomic. */
 #define NERF_HIP_ADAM_MAX_TENSORS 64
+#define NERF_HIP_ADAM_STEP_SLOTS 512
 typedef struct NerfHipAdamArgs {
     int32_t num_tensors;
     int64_t total;                                      /* parameters in all                         */
@@ -260,8 +262,7 @@ typedef struct NerfHipAdamArgs {
     const float* grads[NERF_HIP_ADAM_MAX_TENSORS];      /* one per tensor (views of a flat gradient or not) */
     float* exp_avg;                                     /* [total] first moment                      */
     float* exp_avg_sq;                                  /* [total] second moment                     */
-    float* step;                                        /* [1] device: updates applied so far (read, then + 1) */
-    uint32_t* done;                                     /* [1] device: 0 between launches            */
+    float* step;                                        /* [NERF_HIP_ADAM_STEP_SLOTS] device: updates applied so far */
     float lr, beta1, beta2, eps;
 } NerfHipAdamArgs;
 

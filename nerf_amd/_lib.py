@@ -73,6 +73,7 @@ class LegacyBackwardArgs(ctypes.Structure):
 
 
 ADAM_MAX_TENSORS = 64
+ADAM_STEP_SLOTS = 512
 
 
 class AdamArgs(ctypes.Structure):
@@ -80,7 +81,7 @@ class AdamArgs(ctypes.Structure):
     _fields_ = [("num_tensors", ctypes.c_int32), ("total", ctypes.c_int64),
                 ("offsets", ctypes.c_int64 * (ADAM_MAX_TENSORS + 1)),
                 ("params", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grads", ctypes.c_void_p * ADAM_MAX_TENSORS),
-                ("exp_avg", _f32p), ("exp_avg_sq", _f32p), ("step", _f32p), ("done", ctypes.c_void_p),
+                ("exp_avg", _f32p), ("exp_avg_sq", _f32p), ("step", _f32p),
                 ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 

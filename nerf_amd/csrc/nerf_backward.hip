@@ -337,10 +337,7 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
         const int ge = ((int)blockIdx.x - direct_blocks) * 4 + (threadIdx.x >> 6);   // [layer][gamma|beta][256]
         const int L = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
         const float* p = ba.gb_partial + ge;
-        float sum = 0.f;
-        for (int q = lane; q < ba.data_grid; q += 64) sum += p[(int64_t)q * kGbFloats];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float sum = wave_strided_sum(p, ba.data_grid, kGbFloats, lane);
         if (lane == 0) ba.grad[grad_offset(4 * L + 2 + which, ba.a.num_outputs) + idx] = sum;
         return;
     }

@@ -825,12 +825,35 @@ __device__ __forceinline__ float strided_sum(const float* p, int n, int64_t stri
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] += v[q];
     }
-    for (; i < n; ++i) acc[0] += p[(int64_t)i * stride];
+    if (i < n) {                          // the tail as ONE more round trip (a scalar loop would be n - i of them)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = i + q < n ? p[(int64_t)(i + q) * stride] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += v[q];
+    }
 #pragma unroll
     for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
         for (int q = 0; q < w; ++q) acc[q] += acc[q + w];
     return acc[0];
+}
+
+// One wave sums n partials p[0], p[stride], ...: lane l takes l, l + 64, ... with four loads in flight per round
+// trip, then the lanes combine in a fixed butterfly (one fixed association; every lane returns the sum).
+__device__ __forceinline__ float wave_strided_sum(const float* p, int n, int64_t stride, int lane) {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = lane; q < n; q += 256) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = q + 64 * k < n ? p[(int64_t)(q + 64 * k) * stride] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] += v[k];
+    }
+    float sum = (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    return sum;
 }
 
 }  // namespace nerf_bwd

@@ -461,10 +461,7 @@ __global__ void nerf_legacy_grad_reduce_kernel(const LBwdArgs ba) {
         const int ge = ((int)blockIdx.x - kReduceDirectBlocks) * 4 + (threadIdx.x >> 6);    // [layer][gamma|beta][256]
         const int l = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
         const float* p = ba.gb_partial + ge;
-        float sum = 0.f;
-        for (int q = lane; q < ba.data_grid; q += 64) sum += p[(int64_t)q * kLGbFloats];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float sum = wave_strided_sum(p, ba.data_grid, kLGbFloats, lane);
         if (lane == 0) ba.grad[legacy_grad_offset(wide_param(l) + 2 + which) + idx] = sum;
         return;
     }

@@ -158,20 +158,21 @@ extern "C" int nerf_hip_resample_pdf(const NerfHipResampleArgs* args, void* stre
 // model (22 or 44 tensors, 0.3-0.6 M parameters) that is ~20 workgroups and 43 us of a 0.4 ms training step
 // at 512 rays per GPU; here one thread owns one parameter (1,190 workgroups, a few microseconds).
 //   m <- b1 m + (1 - b1) g ;  v <- b2 v + (1 - b2) g^2 ;  p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-// t = step[0] + 1 with step[0] in DEVICE memory, so a captured launch replays correctly; the workgroup that
-// retires last (a device counter) stores t back: every workgroup has read the old count by then.
+// t = step[b] + 1 with one copy of the count per workgroup b in DEVICE memory, so a captured launch replays
+// correctly and no workgroup reads a count that another one has already advanced; the workgroups stride over
+// the parameters (NERF_HIP_ADAM_STEP_SLOTS of them at most).
 namespace {
 
 struct AdamKernelArgs {
     NerfHipAdamArgs a;
 };
 
-__global__ void nerf_adam_kernel(const AdamKernelArgs ka) {
+__global__ __launch_bounds__(256) void nerf_adam_kernel(const AdamKernelArgs ka) {
 #pragma clang fp contract(off)
     const NerfHipAdamArgs& a = ka.a;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const float t = a.step[0] + 1.0f;
-    if (e < a.total) {
+    const float t = a.step[blockIdx.x] + 1.0f;
+    const float bc1 = 1.0f - powf(a.beta1, t), bc2 = 1.0f - powf(a.beta2, t);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.total; e += (int64_t)gridDim.x * 256) {
         int lo = 0, hi = a.num_tensors;               // tensor t with offsets[t] <= e < offsets[t + 1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -179,7 +180,6 @@ __global__ void nerf_adam_kernel(const AdamKernelArgs ka) {
         }
         const int64_t i = e - a.offsets[lo];
         const float g = a.grads[lo][i];
-        const float bc1 = 1.0f - powf(a.beta1, t), bc2 = 1.0f - powf(a.beta2, t);
         const float m = a.beta1 * a.exp_avg[e] + (1.0f - a.beta1) * g;
         const float v = a.beta2 * a.exp_avg_sq[e] + (1.0f - a.beta2) * (g * g);
         a.exp_avg[e] = m;
@@ -188,10 +188,7 @@ __global__ void nerf_adam_kernel(const AdamKernelArgs ka) {
         a.params[lo][i] = a.params[lo][i] - (a.lr / bc1) * (m / denom);
     }
     __syncthreads();                                  // every thread of this workgroup holds t
-    if (threadIdx.x == 0 && atomicAdd(a.done, 1u) == gridDim.x - 1) {
-        a.step[0] = t;
-        *a.done = 0u;
-    }
+    if (threadIdx.x == 0) a.step[blockIdx.x] = t;
 }
 
 // mean((pred - target)^2) and its gradient: one workgroup of 1,024 threads, strided partial sums, a fixed tree.
@@ -228,7 +225,7 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: null args");
     const NerfHipAdamArgs& a = *args;
     if (a.num_tensors < 1 || a.num_tensors > NERF_HIP_ADAM_MAX_TENSORS || a.total < 0 || a.step == nullptr ||
-        a.done == nullptr || a.exp_avg == nullptr || a.exp_avg_sq == nullptr)
+        a.exp_avg == nullptr || a.exp_avg_sq == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: tensor count / state pointers out of range");
     if (a.offsets[0] != 0 || a.offsets[a.num_tensors] != a.total)
         return nerf_common::fail(NERF_HIP_EINVAL, "adam_step: offsets must run from 0 to total");
@@ -238,9 +235,8 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     if (a.total == 0) return NERF_HIP_OK;
     AdamKernelArgs ka;
     ka.a = a;
-    const int threads = 256;
-    const int64_t blocks = (a.total + threads - 1) / threads;
-    hipLaunchKernelGGL(nerf_adam_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, ka);
+    // every launch uses ALL the slots (idle workgroups only count), so the copies stay equal whatever `total` is
+    hipLaunchKernelGGL(nerf_adam_kernel, dim3(NERF_HIP_ADAM_STEP_SLOTS), dim3(256), 0, (hipStream_t)stream, ka);
     return nerf_common::check_hip(hipGetLastError(), "adam_step launch");
 }
 

@@ -14,22 +14,32 @@ import torch
 from . import _lib
 
 
+def _check(pred, target):
+    if (pred.dim() != 3 or pred.shape[-1] != 3 or target.shape != (pred.shape[0], 3) or not pred.is_cuda
+            or pred.dtype != torch.float32 or target.dtype != torch.float32 or target.device != pred.device):
+        raise ValueError("nerf_amd.loss.mse: pred [N, stages, 3] and target [N, 3], float32, on one ROCm device")
+
+
+def _launch(pred, target):
+    """(loss [], d loss / d pred) of contiguous ``pred`` [N, stages, 3] against ``target`` [N, 3]: one launch."""
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred)
+    args = _lib.MseArgs()
+    args.pred, args.target = _lib.ptr(pred), _lib.ptr(target)
+    args.n_rays, args.stages = pred.shape[0], pred.shape[1]
+    args.loss, args.grad = _lib.ptr(loss), _lib.ptr(grad)
+    with torch.cuda.device(pred.device):
+        stream = torch.cuda.current_stream(pred.device).cuda_stream
+        _lib.check(_lib.lib().nerf_hip_mse_loss(ctypes.byref(args), ctypes.c_void_p(stream)), "nerf_hip_mse_loss")
+    return loss.reshape(()), grad
+
+
 class _MseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
-        n, stages = pred.shape[0], pred.shape[1]
-        pred_c, target_c = pred.contiguous(), target.contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        grad = torch.empty_like(pred_c)
-        args = _lib.MseArgs()
-        args.pred, args.target = _lib.ptr(pred_c), _lib.ptr(target_c)
-        args.n_rays, args.stages = n, stages
-        args.loss, args.grad = _lib.ptr(loss), _lib.ptr(grad)
-        with torch.cuda.device(pred.device):
-            stream = torch.cuda.current_stream(pred.device).cuda_stream
-            _lib.check(_lib.lib().nerf_hip_mse_loss(ctypes.byref(args), ctypes.c_void_p(stream)), "nerf_hip_mse_loss")
+        loss, grad = _launch(pred.contiguous(), target.contiguous())
         ctx.save_for_backward(grad)
-        return loss.reshape(())
+        return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
@@ -42,7 +52,18 @@ def mse(pred, target):
     ROCm device; differentiable with respect to ``pred``."""
     if pred.dim() == 2:
         return mse(pred.unsqueeze(1), target)
-    if (pred.dim() != 3 or pred.shape[-1] != 3 or target.shape != (pred.shape[0], 3) or not pred.is_cuda
-            or pred.dtype != torch.float32 or target.dtype != torch.float32 or target.device != pred.device):
-        raise ValueError("nerf_amd.loss.mse: pred [N, stages, 3] and target [N, 3], float32, on one ROCm device")
+    _check(pred, target)
     return _MseFunction.apply(pred, target)
+
+
+def mse_and_grad(pred, target):
+    """``(loss, d loss / d pred)`` without autograd: what a training loop needs to call ``pred.backward(grad)``
+    itself — no unit root gradient to fill, no scaling of the saved gradient by it (two launches less than
+    ``mse(pred, target).backward()``; ``nerf_amd.trainer.Trainer`` steps this way)."""
+    shape = pred.shape
+    if pred.dim() == 2:
+        pred = pred.unsqueeze(1)
+    _check(pred, target)
+    with torch.no_grad():
+        loss, grad = _launch(pred.detach().contiguous(), target.contiguous())
+    return loss, grad.reshape(shape)

@@ -27,7 +27,7 @@ class Adam(torch.optim.Optimizer):
         if not 1 <= len(self._params) <= _lib.ADAM_MAX_TENSORS:
             raise ValueError(f"nerf_amd.optim.Adam takes 1 .. {_lib.ADAM_MAX_TENSORS} parameter tensors")
         self._flat = None
-        self._done = None
+        self._steps = None
 
     def _state(self):
         if self._flat is None:
@@ -37,12 +37,24 @@ class Adam(torch.optim.Optimizer):
                     raise RuntimeError("nerf_amd.optim.Adam: parameters must be contiguous float32 tensors on one "
                                        "ROCm device")
             total = sum(p.numel() for p in self._params)
+            # the step count: one copy per workgroup of the launch (include/nerf_hip.h), all equal; state shows [0]
+            self._steps = torch.zeros(_lib.ADAM_STEP_SLOTS, dtype=torch.float32, device=dev)
             self._flat = dict(exp_avg=torch.zeros(total, dtype=torch.float32, device=dev),
                               exp_avg_sq=torch.zeros(total, dtype=torch.float32, device=dev),
-                              step=torch.zeros(1, dtype=torch.float32, device=dev))
-            self._done = torch.zeros(1, dtype=torch.int32, device=dev)      # the kernel's retirement counter
+                              step=self._steps[:1])
             self.state["flat"] = self._flat          # (visible through state_dict())
         return self._flat
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces ``state["flat"]`` by copies; the kernel's buffers take their values."""
+        super().load_state_dict(state_dict)
+        loaded = self.state.get("flat")
+        if loaded is not None:
+            self._flat = None
+            st = self._state()
+            st["exp_avg"].copy_(loaded["exp_avg"].reshape(-1))
+            st["exp_avg_sq"].copy_(loaded["exp_avg_sq"].reshape(-1))
+            self._steps.fill_(float(loaded["step"].reshape(-1)[0]))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,8 +78,8 @@ class Adam(torch.optim.Optimizer):
             off += p.numel()
         args.offsets[len(self._params)] = off
         args.total = off
-        args.exp_avg, args.exp_avg_sq, args.step = _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(st["step"])
-        args.done = self._done.data_ptr()             # (the step count is read AND incremented on the device)
+        # (the step count is read AND incremented on the device, by the kernel itself)
+        args.exp_avg, args.exp_avg_sq, args.step = _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(self._steps)
         args.lr, (args.beta1, args.beta2), args.eps = float(group["lr"]), group["betas"], float(group["eps"])
         dev = self._params[0].device
         with torch.cuda.device(dev):

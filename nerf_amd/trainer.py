@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .dataset import PixelRayDataset
-from .loss import mse
+from .loss import mse_and_grad
 from .model import NeRF
 from . import parallel
 
@@ -184,12 +184,17 @@ class Trainer:
                                                           # its backward launches nothing (a select would: zeros + copy)
 
     @staticmethod
-    def _loss(pixels, target):
-        """The loop's MSE (train_conditional_nerf.py:132).  On the GPU: loss and gradient in one launch
-        (nerf_amd.loss.mse); an empty shard (tail of an epoch) gives 0, not NaN, either way."""
+    def _loss_backward(pixels, target):
+        """The loop's ``loss = MSE; loss.backward()`` (train_conditional_nerf.py:132-133); returns the loss.
+        On the GPU the loss and its gradient come from one launch (nerf_amd.loss) and the backward starts at
+        ``pixels`` with that gradient; an empty shard (tail of an epoch) gives loss 0, not NaN, either way."""
         if pixels.is_cuda:
-            return mse(pixels, target)
-        return ((pixels - target) ** 2).sum() / max(pixels.numel(), 1)
+            loss, grad = mse_and_grad(pixels, target)
+            pixels.backward(grad)
+            return loss
+        loss = ((pixels - target) ** 2).sum() / max(pixels.numel(), 1)
+        loss.backward()
+        return loss.detach()
 
     # ---- HIP-graph path ---------------------------------------------------------------------------
     def _graph_body(self, o, d, pix):
@@ -197,11 +202,10 @@ class Trainer:
         u, noise = self._draw(n, dev, None)               # graph-safe default generator
         self.last_draws = (u, noise)                      # (static tensors of the graph once captured)
         pixels = self._render(o, d, u, noise)
-        loss = self._loss(pixels, pix)
-        loss.backward()
+        loss = self._loss_backward(pixels, pix)
         if not self.distributed:
             self.optimizer.step()
-        return loss.detach()
+        return loss
 
     def _graph_step(self, batch):
         """Steps 0-2 run eagerly (lazy initialisation, optimiser state), steps 3-4 eagerly on the side
@@ -268,8 +272,7 @@ class Trainer:
         self.last_draws = (u, noise)                      # what this step rendered with (None: in-kernel Philox)
         pixels = self._render(batch["rays_o"], batch["rays_d"], u, noise)
         self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
-        loss = self._loss(pixels, batch["pixels"])
-        loss.backward()
+        loss = self._loss_backward(pixels, batch["pixels"])
         if self.distributed:
             self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
         self.optimizer.step()

@@ -3,7 +3,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF, _lib
 from nerf_amd.optim import Adam
-from nerf_amd.loss import mse
+from nerf_amd.loss import mse_and_grad
 dev = torch.device('cuda:0')
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
 torch.manual_seed(0)
@@ -13,8 +13,8 @@ opt = Adam(model.parameters(), lr=1e-4)                               # as nerf_
 o = torch.randn(n, 3, device=dev); d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 def step():
     rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0)
-    loss = mse(rgb, tgt)
-    opt.zero_grad(); loss.backward(); opt.step()
+    loss, grad = mse_and_grad(rgb, tgt)
+    opt.zero_grad(); rgb.backward(grad); opt.step()
     return loss
 for _ in range(3): step()
 torch.cuda.synchronize()

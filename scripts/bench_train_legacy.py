@@ -4,7 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd.legacy import LegacyNeRF8x256, FLOP_PER_SAMPLE
 from nerf_amd.optim import Adam
-from nerf_amd.loss import mse
+from nerf_amd.loss import mse_and_grad
 dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -15,8 +15,8 @@ opt = Adam(model.parameters(), lr=1e-4)
 o = torch.randn(n, 3, device=dev) * 0.5; d = torch.randn(n, 3, device=dev); tgt = torch.rand(n, 3, device=dev)
 def step():
     rgb = model.render_rays(o, d, 2.0, 6.0, S, randomly_sample=True, density_noise_std=1.0)
-    loss = mse(rgb, tgt)
-    opt.zero_grad(); loss.backward(); opt.step()
+    loss, grad = mse_and_grad(rgb, tgt)
+    opt.zero_grad(); rgb.backward(grad); opt.step()
     return loss
 for _ in range(3): step()
 torch.cuda.synchronize()

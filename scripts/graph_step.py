@@ -4,7 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_amd import NeRF
 from nerf_amd.optim import Adam
-from nerf_amd.loss import mse
+from nerf_amd.loss import mse_and_grad
 dev = torch.device("cuda:0")
 n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 64
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
@@ -17,8 +17,8 @@ u = torch.rand(n, S, device=dev); noise = torch.randn(n, S - 1, 1, device=dev)
 
 def step():
     rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0, u=u, noise=noise)
-    loss = mse(rgb, tgt)
-    loss.backward()
+    loss, grad = mse_and_grad(rgb, tgt)
+    rgb.backward(grad)
     opt.step()
     return loss
 
@@ -52,4 +52,4 @@ for _ in range(50):
     g.replay()
 torch.cuda.synchronize(); graphed = (time.perf_counter() - t0) / 50
 print(f"{n} rays x {S} [{prec}]: eager {eager*1e3:.3f} ms/step, graph replay {graphed*1e3:.3f} ms/step, "
-      f"parameters move on replay: {changed}, loss {float(static_loss):.4f}")
+      f"parameters move on replay: {changed}, loss {float(static_loss.detach()):.4f}")

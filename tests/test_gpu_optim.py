@@ -95,14 +95,14 @@ def test_fused_mse_is_the_loops_loss_and_autograds_gradient(shape):
     want.backward()
     got = mse(pred, target)
     got.backward()
-    assert got.shape == () and abs(float(got) - float(want)) <= 2e-6 * float(want)
+    assert got.shape == () and abs(float(got.detach()) - float(want.detach())) <= 2e-6 * float(want.detach())
     assert torch.equal(pred.grad, ref_pred.grad)
     # an upstream factor (a weighted sum of losses) scales the gradient like autograd does
     pred.grad = None
     (3.0 * mse(pred, target)).backward()
     assert torch.allclose(pred.grad, 3.0 * ref_pred.grad, rtol=1e-6, atol=0.0)
     # reproducible: one workgroup, a fixed summation order
-    assert float(mse(pred, target)) == float(got)
+    assert float(mse(pred, target).detach()) == float(got.detach())
 
 
 def test_fused_mse_of_an_empty_shard_is_zero():
@@ -114,3 +114,39 @@ def test_fused_mse_of_an_empty_shard_is_zero():
     assert float(loss) == 0.0 and pred.grad.shape == (0, 1, 3)
     with pytest.raises(ValueError):
         mse(torch.zeros(4, 2, device=dev), torch.zeros(4, 3, device=dev))
+
+
+def test_mse_and_grad_is_the_same_launch_without_autograd():
+    from nerf_amd.loss import mse, mse_and_grad
+    dev = torch.device("cuda:0")
+    pred = torch.rand(300, 1, 3, device=dev).requires_grad_(True)
+    target = torch.rand(300, 3, device=dev)
+    loss, grad = mse_and_grad(pred, target)
+    want = mse(pred, target)
+    want.backward()
+    assert not loss.requires_grad and float(loss) == float(want.detach()) and torch.equal(grad, pred.grad)
+    loss2, grad2 = mse_and_grad(pred[:, 0], target)            # [N, 3] predictions
+    assert float(loss2) == float(loss) and torch.equal(grad2, grad[:, 0])
+
+
+def test_adam_state_round_trips_through_state_dict():
+    from nerf_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    p = [torch.randn(40, 7, device=dev, requires_grad=True), torch.randn(9, device=dev, requires_grad=True)]
+    q = [t.detach().clone().requires_grad_(True) for t in p]
+    a, b = Adam(p, lr=1e-2), Adam(q, lr=1e-2)
+    grads = [[torch.randn_like(t) for t in p] for _ in range(6)]
+    for k in range(3):
+        for t, u, g in zip(p, q, grads[k]):
+            t.grad, u.grad = g.clone(), g.clone()
+        a.step(), b.step()
+    fresh = Adam(q, lr=1e-2)
+    fresh.load_state_dict(b.state_dict())                       # moments and step count move over
+    assert float(fresh.state_dict()["state"]["flat"]["step"]) == 3.0
+    for k in range(3, 6):
+        for t, u, g in zip(p, q, grads[k]):
+            t.grad, u.grad = g.clone(), g.clone()
+        a.step(), fresh.step()
+    for t, u in zip(p, q):
+        assert torch.equal(t, u)
