@@ -253,7 +253,7 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
  * own slot, so no workgroup reads a count another one has already advanced, a captured launch replays
  * correctly, and counting costs neither a launch nor an atomic. */
 #define NERF_HIP_ADAM_MAX_TENSORS 64
-#define NERF_HIP_ADAM_STEP_SLOTS 512
+#define NERF_HIP_ADAM_STEP_SLOTS 2048
 typedef struct NerfHipAdamArgs {
     int32_t num_tensors;
     int64_t total;                                      /* parameters in all                         */

@@ -73,7 +73,7 @@ class LegacyBackwardArgs(ctypes.Structure):
 
 
 ADAM_MAX_TENSORS = 64
-ADAM_STEP_SLOTS = 512
+ADAM_STEP_SLOTS = 2048
 
 
 class AdamArgs(ctypes.Structure):

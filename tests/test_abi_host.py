@@ -42,22 +42,32 @@ def test_library_exports_every_declared_symbol(handle):
     assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
 
 
-def test_args_struct_matches_header():
-    """Field order/names of the ctypes mirror == the C struct (guards silent ABI drift)."""
-    from nerf_amd import _lib
-    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
-    body = text[text.index("typedef struct NerfHipRenderArgs"):text.index("} NerfHipRenderArgs;")]
+def header_fields(text, name):
+    body = text[text.index(f"typedef struct {name}"):text.index("} " + name + ";")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in body.split("{", 1)[1].split(";"):
         decl = decl.strip()
         if not decl:
             continue
-        names = decl.split(",")
-        first = names[0].split()[-1].lstrip("*")
-        fields.append(first)
-        fields += [n.strip().lstrip("*") for n in names[1:]]
-    assert fields == [f[0] for f in _lib.RenderArgs._fields_]
+        names = re.sub(r"\[[^\]]*\]", "", decl).split(",")          # array bounds carry no name
+        fields.append(names[0].split()[-1])
+        fields += [n.strip() for n in names[1:]]
+    return [f.lstrip("*") for f in fields]
+
+
+def test_args_structs_match_the_header():
+    """Field order/names of every ctypes mirror == its C struct, and the array bounds they share (guards silent
+    ABI drift)."""
+    from nerf_amd import _lib
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    for c_name, mirror in (("NerfHipRenderArgs", _lib.RenderArgs), ("NerfHipAdamArgs", _lib.AdamArgs),
+                           ("NerfHipMseArgs", _lib.MseArgs), ("NerfHipLegacyBackwardArgs", _lib.LegacyBackwardArgs)):
+        assert header_fields(text, c_name) == [f[0] for f in mirror._fields_], c_name
+    defines = dict(re.findall(r"#define (NERF_HIP_\w+) (\d+)", text))
+    assert int(defines["NERF_HIP_ADAM_MAX_TENSORS"]) == _lib.ADAM_MAX_TENSORS
+    assert int(defines["NERF_HIP_ADAM_STEP_SLOTS"]) == _lib.ADAM_STEP_SLOTS
+    assert int(defines["NERF_HIP_ABI_VERSION"]) == _lib.ABI_VERSION
 
 
 def test_argument_errors_do_not_touch_the_gpu(handle):
