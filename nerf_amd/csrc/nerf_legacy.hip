@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void nerf_legacy_composite_fwd_kernel(const Le
 //   * the per-ray compositing state (4 sums, the sample spacing) and the ray wait in 1.4 KiB of LDS while the
 //     MLP runs, so that nothing is spilled (the state is the same in all four lane groups: 16 slots per wave).
 // ---------------------------------------------------------------------------------------------
-constexpr int kLegacyStashBytes = kWavesPerWg * 16 * (4 + 1) * 4;  // per sample slot of a wave: 4 sums + the spacing
+constexpr int kLegacyStashBytes = kWavesPerWg * 16 * (4 + 1 + 1) * 4;  // per sample slot of a wave: 4 sums, the spacing, t0
 constexpr int kLegacyRayStashBytes = kWavesPerWg * 8 * 4;
-constexpr int kLegacyLdsBytesHalf = kLegacyLdsBytes + kLegacyStashBytes + kLegacyRayStashBytes;   // 81,408 B: still 2 / CU
+constexpr int kLegacyLdsBytesHalf = kLegacyLdsBytes + kLegacyStashBytes + kLegacyRayStashBytes;   // 81,664 B: still 2 / CU
 static_assert(2 * kLegacyLdsBytesHalf <= 160 * 1024, "two workgroups per CU");
 
 using nerf_fused::HMoments;
@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
     for (int i = threadIdx.x; i < kLegacySmallFloats; i += 256) small[i] = a.packed[kLegacyHSmallOffset + i];
     f32x4* const stash = (f32x4*)(smem + kLegacyLdsBytes) + (wave * 16 + j);          // this sample slot: 4 sums ...
     float* const stash_dist = (float*)(smem + kLegacyLdsBytes + kWavesPerWg * 16 * 16) + (wave * 16 + j);   // ... spacing
+    // the sample's near fencepost, parked for the re-encoding at L4: evaluating fencepost() again there means global
+    // loads (and, under stratified sampling, their vmcnt(0) waits, which also drain the weight DMA) inside the layer loop
+    float* const stash_t0 = (float*)(smem + kLegacyLdsBytes + kWavesPerWg * 16 * 20) + (wave * 16 + j);
     float* const ray_stash = (float*)(smem + kLegacyLdsBytes + kLegacyStashBytes) + wave * 8;
     LegacyHPipe pipe;
     pipe.init(a.packed + kLegacyHOffset, smem, wave, lane);
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
                 const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
                 const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
+                if (g == 0) *stash_t0 = t0;
                 if (kTrain) {
                     if (g == 0) *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{0.f, 0.f, dist, 0.f};
                 } else if (g == 0) {
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     {
                         const Ray ray = the_ray();
                         float enc[64];
-                        if (p == 1) encode_position(ray, fencepost(a, local, sc), la, g, enc, kX);
+                        if (p == 1) encode_position(ray, *stash_t0, la, g, enc, kX);
                         else encode_direction(ray, __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]),
                                               la, g, enc, kX);
                         split_block(enc, 0, eh[0], el[0]);
