@@ -608,6 +608,51 @@ __device__ __forceinline__ float fencepost(const NerfHipRenderArgs& a, int64_t l
     return t * a.t_scale;
 }
 
+// Fenceposts s .. s + N - 1 at once: the same values as N calls of fencepost() (same operations, selects for
+// its branches), but every global load — table entries, their neighbours, the caller's draws — is issued before
+// the first one is waited for.  Called one after the other, the stratified path's conditional loads wait one by
+// one, a dozen dependent round trips at the head of every chunk (and each wait also drains the weight DMA).
+template <int N>
+__device__ __forceinline__ void fencepost_run(const NerfHipRenderArgs& a, int64_t local, int s, float (&t)[N]) {
+#pragma clang fp contract(off)
+    const int S = a.num_samples;
+    int at[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) at[k] = s + k < S - 1 ? s + k : S - 1;
+    if (a.t_values != nullptr) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = a.t_values[local * S + at[k]];
+        return;
+    }
+    const bool draw = (a.rng_mode & 1) != 0;
+    if (a.u == nullptr && !draw) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = a.t_table[at[k]] * a.t_scale;
+        return;
+    }
+    float cur[N], prev[N], next[N], uu[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        cur[k] = a.t_table[at[k]];
+        prev[k] = a.t_table[at[k] > 0 ? at[k] - 1 : 0];
+        next[k] = a.t_table[at[k] < S - 1 ? at[k] + 1 : S - 1];
+    }
+    if (a.u != nullptr) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) uu[k] = a.u[local * S + at[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            uu[k] = nerf_rng::uniform(a.rng_seed, a.rng_offset, (uint64_t)(a.ray_begin + local), (uint32_t)at[k], 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float lower = at[k] == 0 ? cur[k] : 0.5f * (cur[k] + prev[k]);
+        const float upper = at[k] == S - 1 ? cur[k] : 0.5f * (next[k] + cur[k]);
+        t[k] = (lower + (upper - lower) * uu[k]) * a.t_scale;
+    }
+}
+
 struct Gaussian {
     float mean[3], cov[3];
 };

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
             // (linear in [near, far] for this network, Mildenhall et al. 2020), stratified by u, or
             // explicit per-ray positions
             const int sc = s < S - 1 ? s : S - 1;
-            const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
+            float posts[2];
+            fencepost_run<2>(a, local, sc, posts);
+            const float t0 = posts[0], t1 = posts[1];
             const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
             float pos_act[64];
             encode_position(ray, t0, la, g, pos_act);
@@ -469,7 +471,9 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
             {
                 const Ray ray = the_ray();
                 const float dlen = __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]);
-                const float t0 = fencepost(a, local, sc), t1 = fencepost(a, local, sc + 1);
+                float posts[2];
+                fencepost_run<2>(a, local, sc, posts);
+                const float t0 = posts[0], t1 = posts[1];
                 const float dist = s >= S - 1 ? 1e10f : dlen * (t1 - t0);
                 if (g == 0) *stash_t0 = t0;
                 if (kTrain) {

@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 ray.o[0] = r0.x, ray.o[1] = r0.y, ray.o[2] = r0.z, ray.d[0] = r0.w;
                 ray.d[1] = ray_stash[4], ray.d[2] = ray_stash[5];
             }
-            const float t0 = fencepost(a, local, s);
-            const float t1 = fencepost(a, local, s + 1);
-            const float t2 = fencepost(a, local, s + 2);
+            float posts[3];
+            fencepost_run<3>(a, local, s, posts);
+            const float t0 = posts[0], t1 = posts[1], t2 = posts[2];
             const Gaussian gs = frustum(ray, t0, t1, a.base_radius_sq);
             float dist;
             {
