@@ -97,6 +97,25 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()
     assert handle.nerf_hip_render_backward(ctypes.byref(bargs), None) == -1
+    # the training loop's optimiser and loss launches: argument errors are caught on the host too
+    assert handle.nerf_hip_adam_step(None, None) == -1 and handle.nerf_hip_mse_loss(None, None) == -1
+    adam = _lib.AdamArgs()
+    assert handle.nerf_hip_adam_step(ctypes.byref(adam), None) == -1           # no tensors
+    adam.num_tensors, adam.total = 1, 8
+    adam.offsets[1] = 8
+    adam.exp_avg = adam.exp_avg_sq = adam.step = ctypes.cast(dummy, _lib._f32p)
+    assert handle.nerf_hip_adam_step(ctypes.byref(adam), None) == -1           # null parameter / gradient
+    assert b"null tensor" in handle.nerf_hip_last_error()
+    adam.offsets[1] = 7
+    adam.params[0] = adam.grads[0] = 16
+    assert handle.nerf_hip_adam_step(ctypes.byref(adam), None) == -1           # offsets do not end at total
+    mse = _lib.MseArgs()
+    mse.n_rays, mse.stages = 4, 0
+    assert handle.nerf_hip_mse_loss(ctypes.byref(mse), None) == -1
+    mse.stages = 1
+    mse.loss = ctypes.cast(dummy, _lib._f32p)
+    assert handle.nerf_hip_mse_loss(ctypes.byref(mse), None) == -1             # rays but no tensors
+    assert b"null tensor" in handle.nerf_hip_last_error()
 
 
 def test_mirror_keeps_reference_call_surface():
