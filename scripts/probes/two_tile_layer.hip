@@ -28,7 +28,45 @@ __device__ __forceinline__ void interleave_n() {
     }
 }
 
-constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16;
+constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16, kSpreadDma = 32, kPairUnits = 64, kDmaToRegs = 128;
+
+// the same four 1 KiB fetches as plain loads into registers nobody reads: the texture path's share of a DMA's cost
+template <class Pipe>
+__device__ __forceinline__ void fetch_to_regs(Pipe& pipe) {
+    const char* base = pipe.blob + (size_t)pipe.issue_stage * kStageBytes + pipe.wave * 4096 + pipe.lane * 16;
+    f32x4 a, b, c, d;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(base) : "memory");
+    pipe.issue_stage = (pipe.issue_stage + 1 == kImageStages) ? 0 : pipe.issue_stage + 1;
+    pipe.issue_slot = (pipe.issue_slot + 1 == kRing) ? 0 : pipe.issue_slot + 1;
+}
+
+// one 1 KiB piece of the stage the pipe would issue next (WeightPipe::issue, piece by piece); the pipe's
+// counters advance with the fourth
+template <int kPiece, class Pipe>
+__device__ __forceinline__ void issue_piece(Pipe& pipe) {
+    const uint32_t dst = (uint32_t)(uintptr_t)(pipe.ring + pipe.issue_slot * kStageBytes + pipe.wave * 4096);
+    uint32_t m0_saved;
+    const char* base = pipe.blob + (size_t)pipe.issue_stage * kStageBytes + pipe.wave * 4096;
+    const uint64_t base_u = (uint64_t)(uintptr_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+    const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 2\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:%c4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(m0_saved)
+        : "v"(pipe.lane * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase), "n"(kPiece * 1024)
+        : "memory");
+    if (kPiece == 3) {
+        pipe.issue_stage = (pipe.issue_stage + 1 == kImageStages) ? 0 : pipe.issue_stage + 1;
+        pipe.issue_slot = (pipe.issue_slot + 1 == kRing) ? 0 : pipe.issue_slot + 1;
+    }
+}
 
 // layer_fused_h (inference, Linear -> LayerNorm -> ReLU order) for two sample tiles that share every
 // A operand: unit = two ds_read_b128 and SIX MFMAs, the two tiles' MFMAs alternate.
@@ -167,7 +205,8 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
         return (const h8*)pipe.open_stage();
     };
     auto next = [&]() {
-        if (!(kFlags & kNoDma)) pipe.prefetch_next();
+        if (kFlags & kDmaToRegs) fetch_to_regs(pipe);
+        else if (!(kFlags & kNoDma)) pipe.prefetch_next();
     };
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = open();
@@ -195,7 +234,12 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
                     ah[pset] = st[(2 * ip) * 64];
                     al[pset] = st[(2 * ip + 1) * 64];
                 }
-                if (ip == 0) next();
+                if (kFlags & kSpreadDma) {           // one piece behind each of the next four units' first MFMA
+                    if (ip == 0) issue_piece<0>(pipe);
+                    if (ip == 1) issue_piece<1>(pipe);
+                    if (ip == 2) issue_piece<2>(pipe);
+                    if (ip == 3) issue_piece<3>(pipe);
+                } else if (ip == 0) next();
             }
             if (build_next && (i == 0 || i == 2)) {
                 ga = norm.gam[i == 0 ? ta : tb];
@@ -488,6 +532,8 @@ int main() {
         run_ablation<kNoBuild | kNoMoments>(a, lds, e0, e1, "no build, no moments");
         run_ablation<kNoDma | kNoBarrier | kNoReads>(a, lds, e0, e1, "no DMA, barrier, reads");
         run_ablation<kNoDma | kNoBarrier | kNoReads | kNoBuild | kNoMoments>(a, lds, e0, e1, "MFMAs only");
+        run_ablation<kSpreadDma>(a, lds, e0, e1, "LDS-DMA pieces spread over four units");
+        run_ablation<kDmaToRegs>(a, lds, e0, e1, "same fetches into registers, not LDS");
         printf("two-tile loop (one wave per SIMD), same switches:\n");
         run_two<0>(a, lds, e0, e1, "as written");
         run_two<kNoDma>(a, lds, e0, e1, "no LDS-DMA issue");
