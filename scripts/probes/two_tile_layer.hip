@@ -19,6 +19,52 @@ using namespace nerf_fused;
 constexpr int kImageStages = 64;                 // four hidden layers of 16 stages
 typedef WeightPipe<kImageStages> ProbePipe;
 
+
+// WeightPipe for ONE workgroup of eight waves per CU sharing the ring: every stage is fetched once for all
+// eight (two 1 KiB pieces per wave), half the weight stream per sample of the product's two 4-wave workgroups.
+struct Pipe8 {
+    const char* blob;
+    char* ring;
+    int issue_stage, issue_slot, read_slot, wave, lane;
+    __device__ __forceinline__ void init(const void* image, char* lds_ring, int w, int l) {
+        blob = (const char*)image, ring = lds_ring, issue_stage = issue_slot = read_slot = 0, wave = w, lane = l;
+    }
+    __device__ __forceinline__ void issue() {
+        const uint32_t dst = (uint32_t)(uintptr_t)(ring + issue_slot * kStageBytes + wave * 2048);
+        uint32_t m0_saved;
+        const char* base = blob + (size_t)issue_stage * kStageBytes + wave * 2048;
+        const uint64_t base_u = (uint64_t)(uintptr_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+        const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 2\n\t"
+            "global_load_lds_dwordx4 %1, %3\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0_saved)
+            : "v"(lane * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase)
+            : "memory");
+        issue_stage = (issue_stage + 1 == kImageStages) ? 0 : issue_stage + 1;
+        issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
+    }
+    template <int kYounger = 0>
+    __device__ __forceinline__ const f32x4* open_stage() {
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
+        read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
+        return p;
+    }
+    __device__ __forceinline__ void prefetch_next() {
+        asm volatile("" ::: "memory");
+        issue();
+    }
+};
+
 template <int kValu, int kMfma>
 __device__ __forceinline__ void interleave_n() {
 #pragma unroll
@@ -28,7 +74,7 @@ __device__ __forceinline__ void interleave_n() {
     }
 }
 
-constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16, kSpreadDma = 32, kPairUnits = 64, kDmaToRegs = 128;
+constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16, kSpreadDma = 32, kPairUnits = 64, kDmaToRegs = 128, kHalfReads = 256;
 
 // the same four 1 KiB fetches as plain loads into registers nobody reads: the texture path's share of a DMA's cost
 template <class Pipe>
@@ -232,7 +278,8 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
                 if (ip == 0) st = open();
                 if (!(kFlags & kNoReads)) {
                     ah[pset] = st[(2 * ip) * 64];
-                    al[pset] = st[(2 * ip + 1) * 64];
+                    if (kFlags & kHalfReads) al[pset] = ah[pset];
+                    else al[pset] = st[(2 * ip + 1) * 64];
                 }
                 if (kFlags & kSpreadDma) {           // one piece behind each of the next four units' first MFMA
                     if (ip == 0) issue_piece<0>(pipe);
@@ -452,6 +499,49 @@ int run_ablation(const Args& a, int lds, hipEvent_t e0, hipEvent_t e1, const cha
     return 0;
 }
 
+
+// The product's one-tile loop in one 8-wave workgroup per CU on a shared ring (Pipe8).
+__global__ __launch_bounds__(512, 1) void shared_ring_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    float* small = (float*)(smem + kRingBytes);
+    for (int i = threadIdx.x; i < 3 * kSmallArrayLds; i += 512)
+        small[i] = i < kSmallArrayLds ? 0.01f : i < 2 * kSmallArrayLds ? 1.0f : 0.05f;
+    Pipe8 pipe;
+    pipe.init(a.image, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+    const f32x4* gam = (const f32x4*)(small + kSmallArrayLds + g * kSmallGStride);
+    const f32x4* bet = (const f32x4*)(small + 2 * kSmallArrayLds + g * kSmallGStride);
+    const float eps = 1e-5f * 4096.f * 4096.f;
+    float total = 0.f;
+    for (int it = 0; it < a.items; ++it) {
+        f32x4 X[16], Y[16];
+        const float sv = a.seed[lane] + (float)it;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) X[T] = f32x4{sv + T, sv - T, sv * 0.5f + T, sv * 0.25f - T};
+        LazyNorm norm;
+        norm.rstd = 0.01f, norm.shift = 0.f, norm.gam = gam, norm.bet = bet, norm.save_row = nullptr;
+        HMoments mom;
+#pragma unroll 1
+        for (int L = 0; L < 2; ++L) {
+            bias16(small, g, Y);
+            layer_fused_h<8, true, false>(pipe, X, Y, norm, mom);
+            norm = finish_moments_at<false, HMoments>(mom, Y, gam, bet, g, nullptr, nullptr, eps);
+            bias16(small, g, X);
+            layer_fused_h<8, true, false>(pipe, Y, X, norm, mom);
+            norm = finish_moments_at<false, HMoments>(mom, X, gam, bet, g, nullptr, nullptr, eps);
+        }
+#pragma unroll
+        for (int T = 0; T < 16; ++T) total += (X[T].x + X[T].y) * norm.rstd;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (total == 12345.678f) a.sink[threadIdx.x] = total;
+}
+
 template <int kFlags>
 int run_two(const Args& a, int lds, hipEvent_t e0, hipEvent_t e1, const char* what) {
     if (hipFuncSetAttribute((const void*)two_tile_kernel<kFlags>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
@@ -534,6 +624,24 @@ int main() {
         run_ablation<kNoDma | kNoBarrier | kNoReads | kNoBuild | kNoMoments>(a, lds, e0, e1, "MFMAs only");
         run_ablation<kSpreadDma>(a, lds, e0, e1, "LDS-DMA pieces spread over four units");
         run_ablation<kDmaToRegs>(a, lds, e0, e1, "same fetches into registers, not LDS");
+        run_ablation<kHalfReads>(a, lds, e0, e1, "one of the two A-operand reads per unit");
+        run_ablation<kHalfReads | kNoDma>(a, lds, e0, e1, "one read per unit, no DMA");
+        run_ablation<kNoReads | kNoDma>(a, lds, e0, e1, "no reads, no DMA");
+        {
+            hipFuncSetAttribute((const void*)shared_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                float ms;
+                hipEventRecord(e0);
+                shared_ring_kernel<<<256, 512, lds>>>(a);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                best = ms < best ? ms : best;
+            }
+            const double flop = 512.0 * 4 * a.items * 16 * 4 * 2.0 * 256 * 256 * 3;
+            printf("  %-44s %.3f ms  (%.3f)\n", "one 8-wave workgroup per CU, shared ring", best, flop / (best * 1e-3) / 2.5166e15);
+        }
         printf("two-tile loop (one wave per SIMD), same switches:\n");
         run_two<0>(a, lds, e0, e1, "as written");
         run_two<kNoDma>(a, lds, e0, e1, "no LDS-DMA issue");
