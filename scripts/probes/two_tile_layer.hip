@@ -225,7 +225,7 @@ __device__ __forceinline__ void layer_fused_h2(Pipe& pipe, f32x4 (&in)[2][16], f
 }
 
 // The product's one-tile loop again, with timing-only switches (wrong results): which part of a unit costs what.
-template <int KB, int kFlags, class Pipe>
+template <int KB, int kFlags, int kS = kSets, class Pipe>
 __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16], const LazyNorm& norm,
                                              HMoments& mom) {
     constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
         for (int m = 1; m < KB; ++m) split8(in[2 * m], in[2 * m + 1], bhi[m], blo[m]);
     }
     mom.reset();
-    h8 ah[kSets], al[kSets];
+    h8 ah[kS], al[kS];
     f32x4 ga, be;
     h2 nh[4], nl[4];
     auto open = [&]() -> const h8* {
@@ -257,7 +257,7 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = open();
 #pragma unroll
-    for (int u = 0; u < kSets - 1; ++u) {
+    for (int u = 0; u < kS - 1; ++u) {
         ah[u] = st[(2 * u) * 64];
         al[u] = st[(2 * u + 1) * 64];
     }
@@ -269,12 +269,12 @@ __device__ __forceinline__ void layer_ablate(Pipe& pipe, f32x4 (&in)[16], f32x4 
         const int ta = 2 * m + 2, tb = 2 * m + 3;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int U = 8 * s + i, set = U % kSets;
+            const int U = 8 * s + i, set = U % kS;
             const int T = 8 * half + i;
             out[T] = mfma_h(ah[set], bhi[m], out[T]);
             __builtin_amdgcn_sched_barrier(0);
-            if (U + kSets - 1 < kUnits) {
-                const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
+            if (U + kS - 1 < kUnits) {
+                const int ip = (i + kS - 1) % 8, pset = (U + kS - 1) % kS;
                 if (ip == 0) st = open();
                 if (!(kFlags & kNoReads)) {
                     ah[pset] = st[(2 * ip) * 64];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void two_tile_kernel(const Args a) {
 }
 
 
-template <int kFlags>
+template <int kFlags, int kS = kSets>
 __global__ __launch_bounds__(256, 2) void ablate_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -468,10 +468,10 @@ __global__ __launch_bounds__(256, 2) void ablate_kernel(const Args a) {
 #pragma unroll 1
         for (int L = 0; L < 2; ++L) {
             bias16(small, g, Y);
-            layer_ablate<8, kFlags>(pipe, X, Y, norm, mom);
+            layer_ablate<8, kFlags, kS>(pipe, X, Y, norm, mom);
             norm = finish_moments_at<false, HMoments>(mom, Y, gam, bet, g, nullptr, nullptr, eps);
             bias16(small, g, X);
-            layer_ablate<8, kFlags>(pipe, Y, X, norm, mom);
+            layer_ablate<8, kFlags, kS>(pipe, Y, X, norm, mom);
             norm = finish_moments_at<false, HMoments>(mom, X, gam, bet, g, nullptr, nullptr, eps);
         }
 #pragma unroll
@@ -481,14 +481,14 @@ __global__ __launch_bounds__(256, 2) void ablate_kernel(const Args a) {
     if (total == 12345.678f) a.sink[threadIdx.x] = total;
 }
 
-template <int kFlags>
+template <int kFlags, int kS = kSets>
 int run_ablation(const Args& a, int lds, hipEvent_t e0, hipEvent_t e1, const char* what) {
-    if (hipFuncSetAttribute((const void*)ablate_kernel<kFlags>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)ablate_kernel<kFlags, kS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         float ms;
         hipEventRecord(e0);
-        ablate_kernel<kFlags><<<512, 256, lds>>>(a);
+        ablate_kernel<kFlags, kS><<<512, 256, lds>>>(a);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -624,6 +624,8 @@ int main() {
         run_ablation<kNoDma | kNoBarrier | kNoReads | kNoBuild | kNoMoments>(a, lds, e0, e1, "MFMAs only");
         run_ablation<kSpreadDma>(a, lds, e0, e1, "LDS-DMA pieces spread over four units");
         run_ablation<kDmaToRegs>(a, lds, e0, e1, "same fetches into registers, not LDS");
+        run_ablation<0, 8>(a, lds, e0, e1, "eight A-operand sets (reads seven units ahead)");
+        run_ablation<0, 2>(a, lds, e0, e1, "two A-operand sets (reads one unit ahead)");
         run_ablation<kHalfReads>(a, lds, e0, e1, "one of the two A-operand reads per unit");
         run_ablation<kHalfReads | kNoDma>(a, lds, e0, e1, "one read per unit, no DMA");
         run_ablation<kNoReads | kNoDma>(a, lds, e0, e1, "no reads, no DMA");
