@@ -191,32 +191,36 @@ __global__ __launch_bounds__(256) void nerf_adam_kernel(const AdamKernelArgs ka)
     if (threadIdx.x == 0) a.step[blockIdx.x] = t;
 }
 
-// mean((pred - target)^2) and its gradient: one workgroup of 1,024 threads, strided partial sums, a fixed tree.
+// mean((pred - target)^2) and its gradient: one workgroup of 1,024 threads, strided partial sums, a fixed
+// butterfly per wave, the sixteen waves in order (one association whatever the launch: reproducible).
 struct MseKernelArgs {
     NerfHipMseArgs a;
 };
 
 __global__ __launch_bounds__(1024) void nerf_mse_kernel(const MseKernelArgs ka) {
 #pragma clang fp contract(off)
-    __shared__ float part[1024];
+    __shared__ float part[16];
     const NerfHipMseArgs& a = ka.a;
     const int64_t per_ray = (int64_t)a.stages * 3, count = a.n_rays * per_ray;
     const float inv = 1.0f / (float)(count > 0 ? count : 1);      // autograd: d loss / d sum = 1 / count ...
     float acc = 0.f;
     for (int64_t e = threadIdx.x; e < count; e += 1024) {
-        const int64_t ray = e / per_ray;
-        const int c = (int)(e - ray * per_ray) % 3;
-        const float x = a.pred[e] - a.target[ray * 3 + c];
+        // element e = (ray, stage, channel): the target's is (ray, channel); one stage: the same index
+        const int64_t te = a.stages == 1 ? e : (e / per_ray) * 3 + (e % 3);
+        const float x = a.pred[e] - a.target[te];
         acc += x * x;
         a.grad[e] = inv * (2.0f * x);                              // ... times d x^2 / d x = 2 x, one rounding
     }
-    part[threadIdx.x] = acc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);   // a fixed butterfly per wave ...
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
+    if (threadIdx.x == 0) {                                        // ... and the 16 waves in order
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += part[w];
+        a.loss[0] = sum / (float)(count > 0 ? count : 1);
     }
-    if (threadIdx.x == 0) a.loss[0] = part[0] / (float)(count > 0 ? count : 1);
 }
 
 }  // namespace
