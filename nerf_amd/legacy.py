@@ -167,9 +167,20 @@ class LegacyNeRF8x256(nn.Module):
         self._last_packed = packed
         return packed
 
-    def _check_f16x3_range(self):
+    def _check_f16x3_range(self, training=False):
         """The split-precision kernel holds 2^8 * w and 2^4 * (gamma * x_hat + beta) as f16 pairs
-        (|x_hat| < 16 for 256 features): refuse parameters outside that range instead of saturating."""
+        (|x_hat| < 16 for 256 features): refuse parameters outside that range instead of saturating.
+        The check is a device -> host copy, so — the rule of ``nerf_amd.model.NeRF`` — it runs when a parameter
+        tensor's version or storage changed and otherwise on every 64th split-precision launch; a training
+        forward, whose versions change with every optimiser step, only uses the every-64th rule; never
+        inside a HIP-graph capture (the trainer re-checks between replays)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        self._f16x3_calls = getattr(self, "_f16x3_calls", -1) + 1
+        periodic = self._f16x3_calls % 64 == 0
+        if not periodic and (training or getattr(self, "_f16x3_checked", None) == key):
+            return
         with torch.no_grad():
             linears = [m for m in self.modules() if isinstance(m, nn.Linear)]
             norms = [m for m in self.modules() if isinstance(m, nn.LayerNorm)]
@@ -179,6 +190,27 @@ class LegacyNeRF8x256(nn.Module):
         if w_max * 256.0 >= 65504.0 or act_max * 16.0 >= 65504.0:
             raise ValueError(f"nerf_amd: parameters out of range for precision='f16x3' (max |w| {w_max:.3g}, "
                              f"max 16|gamma|+|beta| {act_max:.3g}); use precision='fp32'")
+        self._f16x3_checked = key
+
+    def _forget_range_check(self):
+        self._f16x3_checked = None
+        self._f16x3_calls = -1
+
+    def load_state_dict(self, *args, **kwargs):
+        """As nn.Module.load_state_dict; the next split-precision launch re-checks the f16 range."""
+        out = super().load_state_dict(*args, **kwargs)
+        self._forget_range_check()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._forget_range_check()
+        return out
+
+    def check_split_precision_range(self):
+        """Force the f16 range check of the parameters now (raises ValueError when they left it)."""
+        self._forget_range_check()
+        self._check_f16x3_range(training=False)
 
     def _table(self, near, far, num_samples, device):
         """Linear sample positions in [near, far] (torch.linspace on the CPU, cached on the device)."""
@@ -234,8 +266,8 @@ class LegacyNeRF8x256(nn.Module):
         precision = self.train_precision if train_workspace is not None else self.precision
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"nerf_amd: precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
-        if precision == "f16x3" and not torch.cuda.is_current_stream_capturing():
-            self._check_f16x3_range()
+        if precision == "f16x3":
+            self._check_f16x3_range(training=train_workspace is not None)
         args = _lib.LegacyArgs()
         self._fill_args(args, n_rays, num_samples, device, near, far, rays_o=rays_o, rays_d=rays_d, cameras=cameras,
                         ray_begin=ray_begin, u=u, noise=noise, density_noise_std=density_noise_std, packed=packed,

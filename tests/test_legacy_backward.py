@@ -315,3 +315,40 @@ def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameter
                 e = rel_err(p.grad.cpu(), ref[k].grad)
                 assert e <= 5e-6 + 8 * noise_floor, (step, k, e, noise_floor)
         ref_opt.step()
+
+
+@pytest.mark.gpu
+def test_split_precision_range_guard_and_its_recheck_under_graph_replay():
+    """The legacy network guards the f16 range of its split-precision operands like the main one: parameters
+    outside it are refused (at the first launch, and again after load_state_dict), and a graph-replayed training
+    run — whose replays execute no host code — is re-checked by the trainer every 64th iteration (a run of 80
+    iterations crosses that point; it once called a method this class did not have)."""
+    from nerf_amd.legacy import LegacyNeRF8x256
+    from nerf_amd.trainer import Trainer
+    if _TRAIN_PRECISION != "f16x3":
+        pytest.skip("split precision only")
+    dev = torch.device("cuda:0")
+    model = make_model(dev, checkpoint()[0])
+    model.precision = "f16x3"
+    o, d = torch.randn(16, 3, device=dev), torch.randn(16, 3, device=dev)
+    with torch.no_grad():
+        model.render_rays(o, d, 2.0, 6.0, 16)                # in range: renders
+        good = {k: v.clone() for k, v in model.state_dict().items()}
+        next(m for m in model.modules() if isinstance(m, torch.nn.Linear)).weight.mul_(1e4)
+        with pytest.raises(ValueError, match="out of range"):
+            model.render_rays(o, d, 2.0, 6.0, 16)
+        model.load_state_dict(good)
+        assert torch.isfinite(model.render_rays(o, d, 2.0, 6.0, 16)).all()
+        bad = {k: (v * 1e4 if k.endswith("block_1.0.weight") else v) for k, v in good.items()}
+        assert any(k.endswith("block_1.0.weight") for k in good)
+        model.load_state_dict(bad)
+        with pytest.raises(ValueError, match="out of range"):
+            model.check_split_precision_range()
+        model.load_state_dict(good)
+    images, poses, focal = lego_scene(dev)
+    run = Trainer(images, poses, focal, batch_size=128, learning_rate=5e-4, num_samples_per_ray=16,
+                  density_noise_std=1.0, log_interval=10 ** 9, model=model, seed=3, graph=True, near=2.0, far=6.0)
+    before = run.evaluate()
+    run.fit(epochs=100, max_iterations=80)
+    assert run._graph is not None and run.iteration + 1 == 80
+    assert run.evaluate() > before
