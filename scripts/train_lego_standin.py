@@ -8,7 +8,8 @@ A fresh LegacyNeRF8x256 is then trained on them with nerf_amd.trainer.Trainer ex
 BASELINE.md's curve for the real data set: ~8 dB at 0, ~23 dB at 1,000, ~32 dB at 40,000 iterations.
 
 usage: python scripts/train_lego_standin.py [iterations] [fp32|f16x3] [graph|eager]
-writes gpurun_out/lego_standin_<arith>.json (iterations, PSNR, seconds) and ..._<arith>.png (truth | render)."""
+writes gpurun_out/lego_standin_<arith>_<graph|eager>_<iterations>.json (iterations, PSNR, seconds) and the same
+name .png (held-out view: truth | render)."""
 import json, math, os, sys, time
 import numpy as np
 import torch
@@ -97,10 +98,11 @@ result = {"what": "examples/example.ipynb cell 8 on a stand-in Lego scene render
           "network": "legacy 8x256", "train_precision": arith, "graph_replay": graph, "batch_rays": 1024,
           "samples_per_ray": 64, "learning_rate": 1e-4, "iterations": done, "train_seconds": train_seconds,
           "ms_per_iteration": 1e3 * train_seconds / max(done, 1), "curve": curve}
-with open(os.path.join(out, f"lego_standin_{arith}.json"), "w") as f:
+tag = f"{arith}_{'graph' if graph else 'eager'}_{done}"
+with open(os.path.join(out, f"lego_standin_{tag}.json"), "w") as f:
     json.dump(result, f, indent=1)
 from PIL import Image
 strip = np.concatenate([(trainer.truth[-1][0].clip(0, 1) * 255).astype(np.uint8),
                         (trainer.rendered[-1][0].clip(0, 1) * 255).astype(np.uint8)], axis=1)
-Image.fromarray(strip).save(os.path.join(out, f"lego_standin_{arith}.png"))
+Image.fromarray(strip).save(os.path.join(out, f"lego_standin_{tag}.png"))
 print(json.dumps({k: v for k, v in result.items() if k != "curve"}))
