@@ -7,7 +7,8 @@ fixture tests/golden/g9_legacy_checkpoint.npz) on the upper hemisphere at the ch
 A fresh LegacyNeRF8x256 is then trained on them with nerf_amd.trainer.Trainer exactly as the notebook does.
 BASELINE.md's curve for the real data set: ~8 dB at 0, ~23 dB at 1,000, ~32 dB at 40,000 iterations.
 
-usage: python scripts/train_lego_standin.py [iterations] [fp32|f16x3] [graph|eager]
+usage: python scripts/train_lego_standin.py [iterations] [fp32|f16x3] [graph|eager] [legacy8x256|mipnerf]
+(mipnerf: the generation-C network of nerf/model.py on the same views — its own log-spaced samples, no near / far)
 writes gpurun_out/lego_standin_<arith>_<graph|eager>_<iterations>.json (iterations, PSNR, seconds) and the same
 name .png (held-out view: truth | render)."""
 import json, math, os, sys, time
@@ -21,6 +22,7 @@ from nerf_amd.trainer import Trainer
 iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 arith = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
 graph = (sys.argv[3] if len(sys.argv) > 3 else "graph") == "graph"
+network = sys.argv[4] if len(sys.argv) > 4 else "legacy8x256"
 dev = torch.device("cuda", 0)
 H = W = 100
 FOCAL = 138.88887889922103            # tiny_nerf's focal length in pixels (the notebook's data file)
@@ -63,7 +65,11 @@ print(f"stand-in scene: {VIEWS} views {H}x{W} rendered from examples/nerf.pth, m
 
 # ---- the notebook's run ------------------------------------------------------------------------------
 torch.manual_seed(0)
-student = LegacyNeRF8x256().to(dev)                       # fresh PyTorch-default initialisation
+if network == "mipnerf":
+    from nerf_amd import NeRF
+    student = NeRF(focal_length=FOCAL).to(dev)
+else:
+    student = LegacyNeRF8x256().to(dev)                   # fresh PyTorch-default initialisation
 student.train_precision = arith
 trainer = Trainer(images, poses, FOCAL, batch_size=1024, learning_rate=1e-4, num_samples_per_ray=64,
                   density_noise_std=1.0, log_interval=1000, model=student, rng="torch", graph=graph,
@@ -95,10 +101,10 @@ for _ in range(epochs):
 out = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out, exist_ok=True)
 result = {"what": "examples/example.ipynb cell 8 on a stand-in Lego scene rendered from examples/nerf.pth",
-          "network": "legacy 8x256", "train_precision": arith, "graph_replay": graph, "batch_rays": 1024,
+          "network": network, "train_precision": arith, "graph_replay": graph, "batch_rays": 1024,
           "samples_per_ray": 64, "learning_rate": 1e-4, "iterations": done, "train_seconds": train_seconds,
           "ms_per_iteration": 1e3 * train_seconds / max(done, 1), "curve": curve}
-tag = f"{arith}_{'graph' if graph else 'eager'}_{done}"
+tag = f"{arith}_{'graph' if graph else 'eager'}_{done}" + ("" if network == "legacy8x256" else "_" + network)
 with open(os.path.join(out, f"lego_standin_{tag}.json"), "w") as f:
     json.dump(result, f, indent=1)
 from PIL import Image
