@@ -481,11 +481,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     backend = None
+    device_index, shared_device = local_rank, False
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        visible = torch.cuda.device_count()
+        if world > visible:
+            # more ranks than GPUs on this (one) node: only as a REHEARSAL of this code path — the driver's own
+            # command line on a one-GPU box.  The ranks share devices, RCCL cannot carry that, the line says so.
+            if not args.allow_gloo:
+                print(f"[bench] {world} ranks but {visible} GPU(s) visible: refusing to measure; --allow-gloo "
+                      "rehearses the path with ranks sharing a device", file=sys.stderr)
+                raise SystemExit(2)
+            device_index, shared_device = local_rank % max(visible, 1), True
+        torch.cuda.set_device(device_index)
         try:                                      # RCCL over xGMI; only barriers + one scalar reduce use it
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if shared_device:
+                raise RuntimeError("ranks share a device (rehearsal)")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
             backend = "nccl"
         except Exception as exc:
             if not args.allow_gloo:               # a multi-GPU line without RCCL is not the measurement asked for
@@ -496,7 +508,7 @@ def main():
             dist.init_process_group("gloo")
             backend = "gloo"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device_index)
 
     from nerf_amd import NeRF, _lib
     torch.manual_seed(0)
@@ -580,6 +592,7 @@ def main():
                              else f"{world} row blocks of one frame" if world > 1 else "one frame, one GPU"),
                 "collectives": "none",
                 "rendezvous_backend": backend,
+                **({"rehearsal": "ranks share a device: not a scaling measurement"} if shared_device else {}),
             },
             "roofline": roofline(args.precision, m["rays_per_rank"], m["kernel_ms"], m["launches"],
                                  world == 1),

@@ -184,3 +184,33 @@ def test_two_ranks_train_the_legacy_network(tmp_path):
     full = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
     assert full.numel() == 638468
     assert (l0["flat"] - full).abs().max() <= 1e-5 * full.abs().max()       # (f16-pair products: ~2^-22 each)
+
+
+def test_the_drivers_multi_gpu_bench_command_runs_as_a_rehearsal(tmp_path):
+    """The driver launches ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W``.  On this one-GPU box the same command runs with
+    ``--allow-gloo`` as a rehearsal (two ranks share the device, barriers over gloo; without the flag it must
+    refuse): every line of the N > 1 path executes — row blocks, barrier + synchronize fences, MAX over ranks,
+    the weak-scaling leg — and the one JSON line says what it was."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+            "2", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    refused = subprocess.run(base, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert refused.returncode != 0 and "refusing to measure" in refused.stderr
+    base[base.index("--master-port") + 1] = str(free_port())
+    run = subprocess.run(base + ["--allow-gloo"], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [x for x in run.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong"
+    assert line["config"]["rendezvous_backend"] == "gloo" and "rehearsal" in line["config"]
+    assert line["config"]["rays_per_gpu"] == 400 * 800 and line["config"]["collectives"] == "none"
+    # two ranks time-share one GPU: the frame takes about as long as on one rank, never half
+    assert 0.5 * 2.2e8 <= line["value"] <= 1.2 * 2.3e8
+    assert line["weak_scaling"]["frames"] == 2 and line["weak_scaling"]["value"] > 0.5 * 2.2e8
