@@ -168,6 +168,17 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
         const bool with_seg = ba.d_seg != nullptr;
 
         float suffix = 0.f;                       // sum_{m in later chunks} q_m w_m
+        // the chunks are a dependent chain (the suffix sum), their loads are not: chunk c - 1 is fetched while
+        // chunk c is worked on
+        f32x4 next_cmp, next_out[4];
+        auto fetch = [&](int c) {
+            const int64_t tile = slot * chunks + c;
+            next_cmp = *(const f32x4*)(ws + ba.comp + (tile * 16 + j) * 4);   // alpha, T, dist, density
+            const float* otile = ws + ba.out + tile * 1024 + lane * 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) next_out[T] = *(const f32x4*)(otile + T * 256);
+        };
+        fetch(chunks - 1);
         for (int c = chunks - 1; c >= 0; --c) {
             const int s = c * kSamplesPerWave + j;
             const bool ok = ray_ok && s < P;
@@ -177,12 +188,12 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
             // ---- compositing backward -> dL/d(out) in accumulator layout ----
             f32x4 dout[4];
             {
-                const f32x4 cmp = *(const f32x4*)(ws + ba.comp + sp * 4);   // alpha, T, dist, density
+                const f32x4 cmp = next_cmp;
                 const float alpha = cmp.x, t_excl = cmp.y, dist = cmp.z, dens = cmp.w;
                 f32x4 out[4];
-                const float* otile = ws + ba.out + tile * 1024 + lane * 4;
 #pragma unroll
-                for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
+                for (int T = 0; T < 4; ++T) out[T] = next_out[T];
+                if (c > 0) fetch(c - 1);
                 const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
                 // colour: logits on lane group 0 (slots 1..3)
                 const float sr = 1.0f / (1.0f + expf(-out[0].y));

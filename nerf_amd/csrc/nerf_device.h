@@ -864,17 +864,28 @@ __device__ __forceinline__ void composite_fwd_body(const NerfHipRenderArgs& a, i
     float* const ws = a.train_workspace;
     RayAccum racc;
     racc.reset();
+    // the chunks of a ray are a dependent chain (the transmittance carry), their loads are not: chunk c + 1 is
+    // fetched while chunk c is composited (the loop was one exposed round trip to HBM per chunk)
+    f32x4 next[4];
+    float next_dist;
+    auto fetch = [&](int c) {
+        const int64_t tile = local * chunks + c;
+        const float* otile = ws + out_off + tile * 1024 + lane * 4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) next[T] = *(const f32x4*)(otile + T * 256);
+        next_dist = ws[comp_off + (tile * 16 + j) * 4 + 2];
+    };
+    fetch(0);
     for (int c = 0; c < chunks; ++c) {
         const int s = c * kSamplesPerWave + j;
         const bool ok = s < P;
-        const int64_t tile = local * chunks + c;
-        const int64_t sp = tile * 16 + j;
+        const int64_t sp = (local * chunks + c) * 16 + j;
         f32x4 out[4];
-        const float* otile = ws + out_off + tile * 1024 + lane * 4;
 #pragma unroll
-        for (int T = 0; T < 4; ++T) out[T] = *(const f32x4*)(otile + T * 256);
+        for (int T = 0; T < 4; ++T) out[T] = next[T];
+        const float dist = next_dist;
+        if (c + 1 < chunks) fetch(c + 1);
         float* comp = ws + comp_off + sp * 4;
-        const float dist = comp[2];
         const float w = composite_chunk<true>(a, P, local, s, ok, lane, out, dist, racc, comp);
         if (a.out_weights != nullptr && ok && lane < 16) a.out_weights[local * P + s] = w;
     }
