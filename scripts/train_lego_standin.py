@@ -49,7 +49,6 @@ with np.load(os.path.join(ROOT, "tests", "golden", "g9_legacy_checkpoint.npz")) 
 teacher = LegacyNeRF8x256()
 teacher.load_state_dict(params)
 teacher = teacher.to(dev)
-rng = np.random.RandomState(0)
 poses = []
 for v in range(VIEWS):                                    # golden-angle spiral over elevations 10 .. 60 degrees
     az = v * math.pi * (3.0 - math.sqrt(5.0))
@@ -76,7 +75,6 @@ trainer = Trainer(images, poses, FOCAL, batch_size=1024, learning_rate=1e-4, num
                   near=2.0, far=6.0)
 curve = []
 torch.cuda.synchronize()
-t0 = time.perf_counter()
 train_seconds = 0.0
 done = 0
 rays_per_epoch = (VIEWS - 1) * H * W
