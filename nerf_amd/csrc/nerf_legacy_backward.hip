@@ -490,15 +490,18 @@ __global__ void nerf_legacy_grad_reduce_kernel(const LBwdArgs ba) {
     ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kLSlabFloats);
 }
 
-// Split-K factor of the weight gradient: every split writes a partial slab of ALL gradients (1.2 MB; 2.7 MB for
-// the legacy network) that the reduce kernel reads back, so at small batches the slab traffic, not the GEMM, sets
-// the time (512 rays x 64 with 128 splits of 8 tiles: 156 MB written + read around 37 us of MFMA work).  24
-// 32-sample tiles per split keep one round of workgroups on the chip at that size (6 jobs x 42 splits = 252) and
-// leave the 4096-ray batch at the 128-split cap.
+// Split-K factor of the weight gradient (nerf_backward.hip: choose_splits has the reasoning): one split per 24
+// 32-sample tiles, but at most 64 here, not the main network's 128 — this network's partial slab is 2.7 MB and
+// its 14 jobs already make 896 workgroups at 64 splits.  4096 rays x 64, weight-gradient + reduce kernel
+// (scripts/ab_kernels.sh): 128 splits 1.315 + 0.085 ms, 96: 1.304 + 0.070, 64: 1.289 + 0.055, 48: 1.348 +
+// 0.047, 32: 1.545 + 0.042.  (The main network measured the other way: 64 splits 0.708 + 0.025 against 0.643 +
+// 0.038 at 128.)
+constexpr int kLegacyMaxSplits = 64;
+static_assert(kLegacyMaxSplits <= kMaxSplits, "the scratch buffer is sized for kMaxSplits slabs");
 int choose_splits(int64_t n_tiles) {
     int64_t s = n_tiles / 24;
     if (s < 1) s = 1;
-    if (s > kMaxSplits) s = kMaxSplits;
+    if (s > kLegacyMaxSplits) s = kLegacyMaxSplits;
     return (int)s;
 }
 
