@@ -5,7 +5,9 @@ weight decay and no amsgrad (train_conditional_nerf.py:106-107, examples/example
 optimiser for parameters on a ROCm device: same constructor arguments (the unsupported options raise), same
 update rule, ``torch.optim.Optimizer`` protocol (``zero_grad``, ``param_groups``, ``state_dict`` with the flat
 moments), and graph-capturable by construction: the step count lives on the device, the kernel itself increments
-it, and every step is ONE kernel launch.  torch's fused multi-tensor kernel needs 43 us for this model's 22 small tensors; at 512
+it, and every step is ONE kernel launch.  (``lr``, ``betas`` and ``eps`` are launch arguments: a captured
+step replays with the values it was captured with — the reference's loops keep them constant; re-capture after
+changing them.)  torch's fused multi-tensor kernel needs 43 us for this model's 22 small tensors; at 512
 rays per GPU (BASELINE config 5 on 8 GPUs) that is a tenth of the training step.
 """
 import ctypes
