@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "nerf_fused.h"
@@ -542,6 +543,145 @@ __global__ __launch_bounds__(512, 1) void shared_ring_kernel(const Args a) {
     if (total == 12345.678f) a.sink[threadIdx.x] = total;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The decomposition section 8 of DESIGN.md names as the way out: a workgroup's 64 samples share their B
+// operands through LDS, each wave owns a 4 x 4 block of (output tile, sample tile) pairs — 8 + 8 ds_read_b128
+// per 48 MFMAs instead of 32 — and only the A half it needs of every k block.  INNER LOOP ONLY: the B exchange
+// buffer is filled once and never rewritten (no LayerNorm, no normalise / split, no cross-wave statistics), so
+// this is an upper bound for such a kernel's layers, measured with the real weight stream (same image, a
+// 4-slot ring: both 16 KiB halves of a k block are resident while the next block's are in flight).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRing4 = 4;
+template <int kWaves>
+struct PipeN {
+    const char* blob;
+    char* ring;
+    int issue_stage, issue_slot, read_slot, wave, lane;
+    __device__ __forceinline__ void init(const void* image, char* lds_ring, int w, int l) {
+        blob = (const char*)image, ring = lds_ring, issue_stage = issue_slot = read_slot = 0, wave = w, lane = l;
+    }
+    __device__ __forceinline__ void issue() {                    // one 16 KiB stage, four pieces per wave
+        constexpr int kShare = kStageBytes / kWaves;          // 4 KiB (four pieces) or 2 KiB (two) per wave
+        const uint32_t dst = (uint32_t)(uintptr_t)(ring + issue_slot * kStageBytes + wave * kShare);
+        uint32_t m0_saved;
+        const char* base = blob + (size_t)issue_stage * kStageBytes + wave * kShare;
+        const uint64_t base_u = (uint64_t)(uintptr_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+        const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+        if (kWaves == 4)
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 2\n\t"
+                "global_load_lds_dwordx4 %1, %3\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(m0_saved)
+                : "v"(lane * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase)
+                : "memory");
+        else
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 2\n\t"
+                "global_load_lds_dwordx4 %1, %3\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(m0_saved)
+                : "v"(lane * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase)
+                : "memory");
+        issue_stage = (issue_stage + 1 == kImageStages) ? 0 : issue_stage + 1;
+        issue_slot = (issue_slot + 1 == kRing4) ? 0 : issue_slot + 1;
+    }
+};
+
+template <int kFlags, int kWaves = 4>
+__global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void gemm_block_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const bbuf = smem + kRing4 * kStageBytes;             // [2][kWaves sample tiles][hi | lo][1 KiB]
+    for (int i = threadIdx.x; i < 4096 * kWaves / 4; i += 64 * kWaves) ((float*)bbuf)[i] = a.seed[i & 63] * 0.001f;
+    PipeN<kWaves> pipe;
+    pipe.init(a.image, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();                                                // k block 0: both halves
+    __syncthreads();
+    // this wave's out tiles: 8 half + 4 quad .. + 3; its four sample tiles: the workgroup's first or second four
+    const int half = (wave >> 1) & 1, quad = wave & 1, side = wave >> 2;
+    float total = 0.f;
+    h8 ah[2][4], al[2][4], bh[2][4], bl[2][4];                   // operand sets of two k blocks (current | next)
+    int blk = 0;                                                 // k blocks handed over so far
+    // hand-over of the next k block — its two stages have landed (nothing else is in flight), every wave has its
+    // operands of the block before in registers (so those slots may be refilled) — then that block's operands
+    // into set `into` and the DMA of the block after it
+    auto advance = [&](auto into_tag) {
+        constexpr int into = decltype(into_tag)::value;
+        if (!(kFlags & kNoBarrier)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("" ::: "memory");
+        const h8* st = (const h8*)((const f32x4*)(pipe.ring + ((pipe.read_slot + half) & (kRing4 - 1)) * kStageBytes) + lane);
+        pipe.read_slot = (pipe.read_slot + 2) & (kRing4 - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[into][t] = st[(2 * (4 * quad + t)) * 64];
+            al[into][t] = st[(2 * (4 * quad + t) + 1) * 64];
+        }
+        const h8* bs = (const h8*)(bbuf + (blk & 1) * (2048 * kWaves) + side * 8192) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bh[into][q] = bs[(2 * q) * 64];
+            bl[into][q] = bs[(2 * q + 1) * 64];
+        }
+        ++blk;
+        if (!(kFlags & kNoDma)) {
+            pipe.issue();
+            pipe.issue();
+        }
+    };
+    advance(std::integral_constant<int, 0>());
+    for (int it = 0; it < a.items; ++it) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                constexpr int dummy = 0;
+                const int cur = kb & 1;
+                // the next block's hand-over and operand reads go out BEFORE this block's MFMAs
+                if (cur == 0) advance(std::integral_constant<int, 1>());
+                else advance(std::integral_constant<int, 0>());
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[t][q] = mfma_h(ah[cur][t], bh[cur][q], acc[t][q]);
+                        acc[t][q] = mfma_h(ah[cur][t], bl[cur][q], acc[t][q]);
+                        acc[t][q] = mfma_h(al[cur][t], bh[cur][q], acc[t][q]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) total += acc[t][q].x + acc[t][q].y;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (total == 12345.678f) a.sink[threadIdx.x] = total;
+}
+
 template <int kFlags>
 int run_two(const Args& a, int lds, hipEvent_t e0, hipEvent_t e1, const char* what) {
     if (hipFuncSetAttribute((const void*)two_tile_kernel<kFlags>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
@@ -643,6 +783,33 @@ int main() {
             }
             const double flop = 512.0 * 4 * a.items * 16 * 4 * 2.0 * 256 * 256 * 3;
             printf("  %-44s %.3f ms  (%.3f)\n", "one 8-wave workgroup per CU, shared ring", best, flop / (best * 1e-3) / 2.5166e15);
+        }
+        {
+            const int lds4 = kRing4 * kStageBytes + 16384;
+            const double flop = 512.0 * 4 * a.items * 16 * 4 * 2.0 * 256 * 256 * 3;
+            auto run = [&](auto kernel, int waves, const char* what) {
+                const int bytes = kRing4 * kStageBytes + 4096 * waves;
+                hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                Args b = a;
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    float ms;
+                    hipEventRecord(e0);
+                    kernel<<<waves == 4 ? 512 : 256, 64 * waves, bytes>>>(b);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    hipEventElapsedTime(&ms, e0, e1);
+                    best = ms < best ? ms : best;
+                }
+                printf("  %-44s %.3f ms  (%.3f)\n", what, best, flop / (best * 1e-3) / 2.5166e15);
+            };
+            // per item a 4-wave workgroup does 4 layers x 8 k blocks x 48 MFMAs x 4 waves = the work of 4 one-tile
+            // items (an 8-wave one of 8): the same total through every variant
+            run(gemm_block_kernel<0, 4>, 4, "4 x 4 blocks per wave, B through LDS (bare loop)");
+            run(gemm_block_kernel<kNoDma, 4>, 4, "  the same without the weight stream");
+            run(gemm_block_kernel<kNoDma | kNoBarrier, 4>, 4, "  without stream and hand-over");
+            run(gemm_block_kernel<0, 8>, 8, "4 x 4 blocks, ONE 8-wave workgroup per CU");
+            run(gemm_block_kernel<kNoDma, 8>, 8, "  the same without the weight stream");
         }
         printf("two-tile loop (one wave per SIMD), same switches:\n");
         run_two<0>(a, lds, e0, e1, "as written");
