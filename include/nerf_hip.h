@@ -212,7 +212,8 @@ typedef struct NerfHipLegacyArgs {
      * t_table [S] (+ u [n,S] for stratified sampling) or t_values [n,S], t_scale, noise [n,S],
      * density_noise_std, packed (nerf_hip_legacy_pack_weights), rgb [n,3], out_weights [n,S],
      * out_raw [n,S,4] = density | color logits, precision (FP32 or F16X3, as for the main network),
-     * train_workspace (training forward, FP32 only; see below).
+     * train_workspace (training forward, FP32 or F16X3; the backward runs in the arithmetic the training
+     * forward was given: it reads `precision` back from this block; see below).
      * seg, out_mean/cov/t, rng_mode and base_radius_sq must be 0 / NULL. */
     NerfHipRenderArgs render;
     float normalize_position;   /* positions are divided by this before encoding (notebook: 6.0) */
@@ -226,8 +227,8 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream);
 
 /* Training of the legacy network — what the notebook's loop does through PyTorch autograd
  * (examples/example.ipynb cell 8: render_rays(...); ((pixels - target) ** 2).mean().backward(); Adam).
- * A forward with render.train_workspace set (nerf_hip_legacy_train_workspace_bytes() bytes; fp32 arithmetic)
- * also saves what the backward needs; nerf_hip_legacy_render_backward then writes the flat gradient:
+ * A forward with render.train_workspace set (nerf_hip_legacy_train_workspace_bytes() bytes; either precision,
+ * the workspace layout is the same for both) also saves what the backward needs; nerf_hip_legacy_render_backward then writes the flat gradient:
  * nerf_hip_legacy_grad_elements() = 638,468 floats, the 44 tensors in the pack routine's order, each in its
  * PyTorch layout.  `fwd` must be the argument block of that training forward.  Rays are not differentiated. */
 #define NERF_HIP_LEGACY_GRAD_ELEMENTS 638468

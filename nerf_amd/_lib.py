@@ -95,6 +95,28 @@ NUM_LEGACY_PARAM_TENSORS = 44
 _lib = None
 
 
+def _check_stamp():
+    """A library older than the sources next to it must not load silently: the ABI number only changes
+    with the header, a kernel edit does not bump it.  ``build.build()`` writes the content hash of
+    everything the library's bytes depend on beside the .so; the in-tree library is refused when that
+    hash is not the hash of the tree it sits in.  A library named through NERF_HIP_LIB (an experimental
+    variant with its own -D list) is the caller's responsibility."""
+    if os.environ.get("NERF_HIP_LIB"):
+        return
+    from . import build
+    try:
+        with open(LIB_PATH + ".stamp") as f:
+            have = f.read().strip().split("-")[0]
+    except OSError:
+        have = None
+    want = build.source_stamp()
+    if have != want:
+        raise RuntimeError(
+            f"{LIB_PATH} is stale: its build stamp ({have and have[:12]}) is not the stamp of the sources "
+            f"under {build.CSRC} ({want[:12]}). Rebuild with `python -c 'import __graft_entry__ as g; "
+            "g.build()'`.")
+
+
 def lib():
     """The loaded library; raises RuntimeError when it has not been built."""
     global _lib
@@ -156,6 +178,7 @@ def lib():
             f"{LIB_PATH} was compiled as an experiment {flags} (-DNERF_HIP_EXPERIMENT: not the product "
             "kernels); rebuild the product library, or select an experimental build explicitly "
             "with NERF_HIP_LIB=<path>")
+    _check_stamp()
     _lib = handle
     return _lib
 

@@ -57,20 +57,30 @@ def _hipcc():
 
 
 def stamp(defines=()):
-    """Hash of everything the library's bytes depend on: source and header CONTENTS (mtimes do not
-    survive a snapshot copy to the GPU box), this file (the flags live here), the scanner's rules,
-    the -D list and the compiler's version string."""
+    """"<tree hash>-<compiler hash>" of everything the library's bytes depend on: source and header
+    CONTENTS (mtimes do not survive a snapshot copy to the GPU box), this file (the flags live here), the
+    scanner's rules and the -D list; then the compiler's version string."""
+    return source_stamp(defines) + "-" + _compiler_id()
+
+
+def _compiler_id():
+    try:
+        out = subprocess.run([_hipcc(), "--version"], capture_output=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        out = b"no-hipcc"           # a box without the compiler can only use what it was given
+    return hashlib.sha256(out).hexdigest()[:16]
+
+
+def source_stamp(defines=()):
+    """The part of ``stamp`` that depends on the tree only (what the loader holds a library to:
+    nerf_amd/_lib.py refuses a library whose sources have changed since it was built)."""
     h = hashlib.sha256()
     for p in sources() + headers() + [os.path.abspath(__file__), isa_scan.__file__]:
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(repr((CODEGEN_FLAGS, sorted(FILE_FLAGS.items()), tuple(defines))).encode())
-    try:
-        h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, timeout=60).stdout)
-    except (OSError, subprocess.SubprocessError):
-        h.update(b"no-hipcc")       # a box without the compiler can only use what it was given
-    return h.hexdigest()
+    return h.hexdigest()[:40]
 
 
 def up_to_date(out=None, defines=()):

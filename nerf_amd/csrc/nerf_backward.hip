@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs b
     CompositeBwd cb;
     cb.d_rgb = ba.d_rgb, cb.d_seg = ba.d_seg;
     cb.intervals = ba.intervals, cb.chunks = ba.chunks;
-    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5 = ba.L.dy5;
+    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5_rows = ba.a.train_workspace + ba.L.dy5;
     composite_bwd_body(ba.a, cb);
 }
 

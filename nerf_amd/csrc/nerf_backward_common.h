@@ -147,7 +147,8 @@ struct CompositeBwd {
     const float* d_seg;         // [n_rays,50] or NULL
     int32_t intervals, chunks;  // samples per ray that are composited, ceil(intervals / 16)
     int64_t mp;                 // padded samples of the workspace
-    int64_t out, comp, dy5;     // workspace offsets: padded outputs (tile), compositing state, dL/d(out) rows
+    int64_t out, comp;          // workspace offsets: padded outputs (tile), compositing state
+    float* dy5_rows;            // [mp][64] dL/d(out) rows, written here (in the workspace or in the backward's scratch)
 };
 __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, const CompositeBwd& ba) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -271,7 +272,7 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
 #pragma unroll
                     for (int T = 0; T < 4; ++T) dout[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                float* drow = ws + ba.dy5 + sp * kOutPad + 4 * g;
+                float* drow = ba.dy5_rows + sp * kOutPad + 4 * g;
 #pragma unroll
                 for (int T = 0; T < 4; ++T) *(f32x4*)(drow + T * 16) = dout[T];
             }

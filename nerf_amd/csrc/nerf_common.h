@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -41,8 +42,8 @@ struct Timing {
         static std::mutex m;
         return m;
     }
-    static bool& on() {
-        static bool v = false;
+    static std::atomic<bool>& on() {      // read on every launch without the mutex
+        static std::atomic<bool> v{false};
         return v;
     }
     static std::vector<Pair>& pairs() {
@@ -54,14 +55,13 @@ struct Timing {
         return e;
     }
     static int enable(bool v) {
-        std::lock_guard<std::mutex> lk(mu());
-        on() = v;
+        on().store(v, std::memory_order_relaxed);
         return NERF_HIP_OK;
     }
     static constexpr size_t kMaxPairs = 8192;   // un-read launches beyond this are not timed
     static void before(hipStream_t st) {
         pending() = nullptr;
-        if (!on()) return;
+        if (!on().load(std::memory_order_relaxed)) return;
         {
             std::lock_guard<std::mutex> lk(mu());
             if (pairs().size() >= kMaxPairs) return;

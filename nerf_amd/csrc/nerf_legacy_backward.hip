@@ -54,6 +54,7 @@ struct LBwdArgs {
     float* dymax;               // [grid][16]: largest |dY| each data-gradient workgroup saw: 0..9 dy[l], 10 the heads'
                                 // rows; split-precision path only
     float* slabs;               // [splits][kLSlabFloats]
+    float* rows;                // the scratch buffer's row area: dY of the ten wide layers, dL/d(out) (L.dy[], L.dy5)
     float* grad;
     int32_t splits, data_grid;
     int64_t tiles_per_split, n_tiles;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void nerf_legacy_composite_bwd_kernel(const LB
     CompositeBwd cb;
     cb.d_rgb = ba.d_rgb, cb.d_seg = nullptr;
     cb.intervals = ba.samples, cb.chunks = ba.chunks;
-    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5 = ba.L.dy5;
+    cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5_rows = ba.rows + ba.L.dy5;
     composite_bwd_body(ba.a, cb);
 }
 
@@ -188,11 +189,11 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
         const int64_t tile = grp * kWavesPerWg + wave;
         const int64_t sp = tile * 16 + j;
         const float* const xbase = ws + sp * kHidden + 4 * g;         // + L.xhat[l]: this lane's a_hat row
-        float* const dybase = ws + sp * kHidden + 4 * g;              // + L.dy[l]
+        float* const dybase = ba.rows + sp * kHidden + 4 * g;              // + L.dy[l]
         const float* const stat = ws + sp;                            // + L.rstd[l] / L.shift[l]
         // dL/d(density, r, g, b) of this sample: k slots (g 0, r 0..3) of BOTH head stages (the transposed
         // head images carry zeros in the slots that are not theirs; lane groups 1..3 read zero columns)
-        const float* const dhead = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+        const float* const dhead = ba.rows + ba.L.dy5 + sp * kOutPad + 4 * g;
         f32x4 xh[16];
         float rstd, shift;
 #pragma unroll
@@ -289,11 +290,11 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
         const int64_t tile = grp * kWavesPerWg + wave;
         const int64_t sp = tile * 16 + j;
         const float* const xbase = ws + sp * kHidden + 4 * g;
-        float* const dybase = ws + sp * kHidden + 4 * g;
+        float* const dybase = ba.rows + sp * kHidden + 4 * g;
         const float* const stat = ws + sp;
         // dL/d(density, r, g, b) on lane group 0 (zeros elsewhere), then a_hat / 1/std / shift of L9: 18 loads
         // that fly under the two stages of the color head
-        const f32x4 dh = *(const f32x4*)(ws + ba.L.dy5 + sp * kOutPad + 4 * g);
+        const f32x4 dh = *(const f32x4*)(ba.rows + ba.L.dy5 + sp * kOutPad + 4 * g);
         f32x4 xh[16];
         float rstd, shift, unscale;
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
                 for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + T * 16);
                 rstd = stat[ba.L.rstd[l - 1]];
                 shift = stat[ba.L.shift[l - 1]];
-                ddens = ws[ba.L.dy5 + sp * kOutPad];
+                ddens = ba.rows[ba.L.dy5 + sp * kOutPad];
                 // the sample's largest |dy|: this layer's B-operand scale, and (folded into the workgroup's
                 // maximum) the weight-gradient kernel's
                 float m = 0.f;
@@ -386,20 +387,20 @@ __global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_kernel(const LBwdArg
     if (job < kHiddenJobs) {
         // wide layer l = job + 1: dY_l against x'_{l-1} = gamma_{l-1} a_hat_{l-1} + beta_{l-1}
         const int l = job + 1;
-        wgrad_body_ring<ShapeHid, kInputAffine>(jb, smem, ws + ba.L.dy[l], ws + ba.L.xhat[l - 1],
+        wgrad_body_ring<ShapeHid, kInputAffine>(jb, smem, ba.rows + ba.L.dy[l], ws + ba.L.xhat[l - 1],
                                                 small + (l - 1) * kLegacySmallPerLayer,
                                                 kLSlabHid + job * kHidden * kHidden, kLSlabB + l * kHidden);
     } else if (job < kHiddenJobs + 3) {
         // the encoding columns: L0 x position, L4 x position, L8 x direction (only L0's bias sums are read)
         const int e = job - kHiddenJobs;
         const int l = e == 0 ? 0 : (e == 1 ? 4 : 8);
-        wgrad_body_ring<ShapeEnc, kInputRaw>(jb, smem, ws + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
+        wgrad_body_ring<ShapeEnc, kInputRaw>(jb, smem, ba.rows + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
                                              kLSlabEnc + e * kHidden * kEncPad, e == 0 ? kLSlabB : kLSlabSpare);
     } else {
         // the heads: rows (d density, d r, d g, d b, 0 ..) against x'_7 (density: row 0) or x'_9 (color: rows 1..3)
         const int h = job - kHiddenJobs - 3;
         const int l = h == 0 ? 7 : 9;
-        wgrad_body_ring<ShapeL5, kInputAffine>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[l],
+        wgrad_body_ring<ShapeL5, kInputAffine>(jb, smem, ba.rows + ba.L.dy5, ws + ba.L.xhat[l],
                                                small + l * kLegacySmallPerLayer, kLSlabHead + h * kOutPad * kHidden,
                                                kLSlabB + kWide * kHidden + h * kOutPad);
     }
@@ -417,18 +418,18 @@ __global__ __launch_bounds__(256, 1) void nerf_legacy_wgrad_h_kernel(const LBwdA
     const float* small = ba.a.packed + kLegacyBlobFloats;
     if (job < kHiddenJobs) {
         const int l = job + 1;
-        wgrad_body_ring<ShapeHid, kInputAffine, true>(jb, smem, ws + ba.L.dy[l], ws + ba.L.xhat[l - 1],
+        wgrad_body_ring<ShapeHid, kInputAffine, true>(jb, smem, ba.rows + ba.L.dy[l], ws + ba.L.xhat[l - 1],
                                                       small + (l - 1) * kLegacySmallPerLayer,
                                                       kLSlabHid + job * kHidden * kHidden, kLSlabB + l * kHidden, l);
     } else if (job < kHiddenJobs + 3) {
         const int e = job - kHiddenJobs;
         const int l = e == 0 ? 0 : (e == 1 ? 4 : 8);
-        wgrad_body_ring<ShapeEnc, kInputRaw, true>(jb, smem, ws + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
+        wgrad_body_ring<ShapeEnc, kInputRaw, true>(jb, smem, ba.rows + ba.L.dy[l], ws + (e == 2 ? ba.L.dir : ba.L.pos), nullptr,
                                                    kLSlabEnc + e * kHidden * kEncPad, e == 0 ? kLSlabB : kLSlabSpare, l);
     } else {
         const int h = job - kHiddenJobs - 3;
         const int l = h == 0 ? 7 : 9;
-        wgrad_body_ring<ShapeL5, kInputAffine, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[l],
+        wgrad_body_ring<ShapeL5, kInputAffine, true>(jb, smem, ba.rows + ba.L.dy5, ws + ba.L.xhat[l],
                                                      small + l * kLegacySmallPerLayer,
                                                      kLSlabHead + h * kOutPad * kHidden,
                                                      kLSlabB + kWide * kHidden + h * kOutPad, 10);
@@ -497,7 +498,7 @@ __global__ void nerf_legacy_grad_reduce_kernel(const LBwdArgs ba) {
 // 0.047, 32: 1.545 + 0.042.  (The main network measured the other way: 64 splits 0.708 + 0.025 against 0.643 +
 // 0.038 at 128.)
 constexpr int kLegacyMaxSplits = 64;
-static_assert(kLegacyMaxSplits <= kMaxSplits, "the scratch buffer is sized for kMaxSplits slabs");
+static_assert(kLegacyMaxSplits <= kMaxSplits, "the ring GEMM's split bookkeeping is sized for kMaxSplits");
 int choose_splits(int64_t n_tiles) {
     int64_t s = n_tiles / 24;
     if (s < 1) s = 1;
@@ -511,7 +512,10 @@ extern "C" {
 
 size_t nerf_hip_legacy_backward_scratch_bytes(int64_t n_rays, int32_t num_samples) {
     if (n_rays <= 0 || num_samples < 2) return 0;
-    return ((size_t)kMaxSplits * kLSlabFloats + (size_t)kMaxDataGrid * (kLGbFloats + 16)) * sizeof(float);
+    const int chunks = (num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
+    const LegacyTrainLayout L = make_legacy_train_layout(n_rays, chunks);
+    return ((size_t)kLegacyMaxSplits * kLSlabFloats + (size_t)kMaxDataGrid * (kLGbFloats + 16) + (size_t)L.bwd_total) *
+           sizeof(float);
 }
 
 int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void* stream) {
@@ -545,8 +549,9 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
     ba.splits = choose_splits(ba.n_tiles);
     ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
     ba.slabs = args->scratch;
-    ba.gb_partial = args->scratch + (size_t)kMaxSplits * kLSlabFloats;
+    ba.gb_partial = args->scratch + (size_t)kLegacyMaxSplits * kLSlabFloats;
     ba.dymax = ba.gb_partial + (size_t)kMaxDataGrid * kLGbFloats;
+    ba.rows = ba.dymax + (size_t)kMaxDataGrid * 16;         // dY / dL/d(out) rows: L.bwd_total floats (16-byte aligned)
 
     int device = 0, cus = 0;
     int rc = nerf_common::check_hip(hipGetDevice(&device), "hipGetDevice");

@@ -136,19 +136,25 @@ __host__ __device__ inline int encoding_column(int f, int freqs) {
     return 16 * (q / 4) + 4 * g + (q % 4);
 }
 
-// ---- saved-for-backward workspace (training forward writes it, backward reads / extends it) --------
+// ---- saved-for-backward workspace (training forward writes it, backward reads it) --------------------
 // padded sample sp = (ray slot * chunks + c) * 16 + j, chunks = ceil(S / 16); "row" tensors [sp][feature].
+// What only the BACKWARD writes and reads — dY of every wide layer, dL/d(out) — is not part of it: those rows
+// live in the backward's scratch buffer (offsets dy[] / dy5 below are relative to THAT area, `bwd_total` floats),
+// which the host caches across steps; the forward's allocation, held from forward to backward, is the first
+// `total` floats only (11.1 instead of 21.6 KB per padded sample).
 struct LegacyTrainLayout {
     int64_t mp;                 // padded samples = ceil4(n_rays) * chunks * 16
     int64_t pos, dir;           // row  [mp, 64]   encoded position / direction (padded columns)
-    int64_t dy[kWide];          // row  [mp, 256]  grad wrt the Linear output y of wide layer L
-    int64_t dy5;                // row  [mp, 64]   grad wrt (density, r, g, b) in columns 0..3, rest 0
     int64_t xhat[kWide];        // row  [mp, 256]  a_hat = (relu(y) - mean) / std of wide layer L
     int64_t rstd[kWide];        // [mp]
     int64_t shift[kWide];       // [mp]            a_hat of a closed ReLU gate: a_hat > shift <=> y > 0
     int64_t out;                // tile [mp, 64]   (density, r, g, b) in the compositing kernels' tile format
     int64_t comp;               // [mp, 4]         alpha, T_exclusive, dist, density(+noise)
-    int64_t total;              // floats
+    int64_t total;              // floats of the workspace
+    // backward-owned rows, offsets into the scratch buffer's row area
+    int64_t dy[kWide];          // row  [mp, 256]  grad wrt the Linear output y of wide layer L
+    int64_t dy5;                // row  [mp, 64]   grad wrt (density, r, g, b) in columns 0..3, rest 0
+    int64_t bwd_total;          // floats of that area
 };
 
 __host__ __device__ inline LegacyTrainLayout make_legacy_train_layout(int64_t n_rays, int chunks) {
@@ -158,14 +164,16 @@ __host__ __device__ inline LegacyTrainLayout make_legacy_train_layout(int64_t n_
     int64_t off = 0;
     t.pos = off; off += t.mp * kEncPad;
     t.dir = off; off += t.mp * kEncPad;
-    for (int i = 0; i < kWide; ++i) { t.dy[i] = off; off += t.mp * kHidden; }
-    t.dy5 = off; off += t.mp * kOutPad;
     for (int i = 0; i < kWide; ++i) { t.xhat[i] = off; off += t.mp * kHidden; }
     for (int i = 0; i < kWide; ++i) { t.rstd[i] = off; off += t.mp; }
     for (int i = 0; i < kWide; ++i) { t.shift[i] = off; off += t.mp; }
     t.out = off; off += t.mp * kOutPad;
     t.comp = off; off += t.mp * 4;
     t.total = off;
+    off = 0;
+    for (int i = 0; i < kWide; ++i) { t.dy[i] = off; off += t.mp * kHidden; }
+    t.dy5 = off; off += t.mp * kOutPad;
+    t.bwd_total = off;
     return t;
 }
 

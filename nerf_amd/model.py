@@ -130,6 +130,7 @@ class NeRF(nn.Module):
         self._packed = None
         self._packed_key = None
         self._tables = {}
+        self._dead_draw_offsets = {}
         self._philox_calls = 0
 
     # ---- statics (reference: nerf/model.py:243-367, :438-469) --------------------------------
@@ -420,6 +421,32 @@ class NeRF(nn.Module):
             noise = None                       # drawn (generator advanced) but adds nothing
         return u, noise, 0
 
+    def _skip_dead_draws(self, ray_lists, num_samples, step, device):
+        """Advance torch's generator of ``device`` as the reference's chunk loop does on the deterministic
+        path: one ``randn([n, S-1, 1])`` per chunk of ``step`` rays of every list (nerf/model.py:652-654,
+        :750-761), without drawing.  How far one such call moves the Philox offset is a property of torch's
+        kernel launch policy on this device, so it is MEASURED once per chunk shape on a private generator
+        and cached, not derived."""
+        if torch.cuda.is_current_stream_capturing():
+            return                                   # a captured region cannot move the host-side offset
+        gen = torch.cuda.default_generators[device.index if device.index is not None
+                                            else torch.cuda.current_device()]
+        advance = 0
+        for count in ray_lists:
+            full, tail = divmod(int(count), step)
+            for n, times in ((step, full), (tail, 1 if tail else 0)):
+                if times == 0:
+                    continue
+                key = (n, int(num_samples), str(device))
+                if key not in self._dead_draw_offsets:
+                    probe = torch.Generator(device=device)
+                    probe.manual_seed(0)
+                    torch.randn(n, num_samples - 1, 1, dtype=torch.float32, device=device, generator=probe)
+                    self._dead_draw_offsets[key] = int(probe.get_offset())
+                advance += times * self._dead_draw_offsets[key]
+        if advance:
+            gen.set_offset(gen.get_offset() + advance)
+
     # ---- the reference's methods -----------------------------------------------------------------
 
     def forward(self, rays_o, rays_d, samples, states_x=None, states_d=None):
@@ -616,12 +643,18 @@ class NeRF(nn.Module):
                               device=device)
         n_rays = rows * image_w
         if not stochastic or self.rng == "philox":
-            # one launch per frame, written straight into the output block.  (On the deterministic
-            # path the reference still draws a randn per chunk that it then multiplies by 0,
-            # model.py:652-654; that dead draw is not reproduced here.)
+            # one launch per frame, written straight into the output block.  On the deterministic path the
+            # reference still draws a randn per chunk that it then multiplies by 0 (model.py:652-654, once
+            # per chunk of its loop :757-761): nothing is drawn here, but with rng="torch" the device
+            # generator is ADVANCED by what those draws consume, so that whatever the caller draws next is
+            # what it would have drawn after the reference's render_image.
             mode = 0
             if stochastic:
                 mode = (1 if randomly_sample else 0) | (2 if density_noise_std != 0.0 else 0)
+            elif self.rng == "torch":
+                total = batch * n_rays
+                self._skip_dead_draws([total] if rows == image_h else [n_rays] * batch, num_samples,
+                                      max(int(max_chunk_size), 1), device)
             for b in range(batch):
                 self._launch(n_rays, num_samples, device, cameras=cameras,
                              ray_begin=(b * image_h + row_begin) * image_w,

@@ -48,15 +48,18 @@ class Adam(torch.optim.Optimizer):
         return self._flat
 
     def load_state_dict(self, state_dict):
-        """torch's loader replaces ``state["flat"]`` by copies; the kernel's buffers take their values."""
+        """torch's loader replaces ``state["flat"]`` by copies; the kernel's buffers take their VALUES and keep
+        their addresses: a HIP graph captured before the load (``Trainer(graph=True)``) has those addresses in
+        its Adam launch and goes on replaying against them, so the loaded moments and step count must land
+        there, not in fresh tensors."""
         super().load_state_dict(state_dict)
         loaded = self.state.get("flat")
         if loaded is not None:
-            self._flat = None
-            st = self._state()
+            st = self._state()                       # existing buffers if there are any, else new ones
             st["exp_avg"].copy_(loaded["exp_avg"].reshape(-1))
             st["exp_avg_sq"].copy_(loaded["exp_avg_sq"].reshape(-1))
             self._steps.fill_(float(loaded["step"].reshape(-1)[0]))
+            self.state["flat"] = st
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -87,4 +90,10 @@ class Adam(torch.optim.Optimizer):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.lib().nerf_hip_adam_step(ctypes.byref(args), ctypes.c_void_p(stream)), "nerf_hip_adam_step")
+        # The kernel wrote the parameters through raw pointers: tell autograd (its in-place-modification guard)
+        # and everything keyed on the version counters (the models' f16 range-check cache) that they changed,
+        # as torch's own optimisers do.  Host-side only, so legal during a capture; a REPLAY runs no host code
+        # at all, which is why the trainer forgets the range check itself between replays.
+        for p in self._params:
+            torch.autograd.graph.increment_version(p)
         return loss

@@ -280,6 +280,9 @@ class Trainer:
 
     def evaluate(self):
         cam_o, cam_r = self.test_pose[..., :3, 3].contiguous(), self.test_pose[..., :3, :3].contiguous()
+        # graph replays update the parameters without running host code (no version bump): the evaluation
+        # render must not trust a range check cached before them
+        self.model._forget_range_check()
         with torch.no_grad():
             if self.legacy:                               # the notebook's call (cell 8)
                 render = self.model.render_image(cam_o, cam_r, self.image_h, self.image_w, self.focal_length,

@@ -84,11 +84,17 @@ def _act(x, cfg):
     return F.relu(x) if cfg["activation"] == "relu" else F.gelu(x)
 
 
-def _block(params, keys, h, cfg):
+def _block(params, keys, h, cfg, gates=None, record=None):
+    """``gates``: an iterator of boolean masks, one per layer, that REPLACE the activation's own decision
+    (relu(y) becomes y * gate): the gradient tests take them from the kernel under test, so that both sides
+    differentiate the same piecewise-linear function (a ReLU gate within rounding of zero is a discontinuity
+    of the gradient, not an error of either side).  ``record``: list that receives each layer's own gates."""
     for lin in keys:
         h = F.linear(h, params[lin + ".weight"], params[lin + ".bias"])
-        h = F.layer_norm(_act(h, cfg), (256,), params[norm_key(lin) + ".weight"],
-                         params[norm_key(lin) + ".bias"], 1e-5)
+        if record is not None:
+            record.append((h > 0).detach())
+        a = _act(h, cfg) if gates is None else h * next(gates).to(h.dtype)
+        h = F.layer_norm(a, (256,), params[norm_key(lin) + ".weight"], params[norm_key(lin) + ".bias"], 1e-5)
     return h
 
 
@@ -96,17 +102,19 @@ def _concat(h, enc, cfg):
     return torch.cat([h, enc] if cfg["concat_order"] == "hidden_first" else [enc, h], dim=-1)
 
 
-def field(params, cfg, points, directions):
-    """density [..., 1], color logits [..., 3] at `points` seen along `directions`."""
+def field(params, cfg, points, directions, gates=None, record=None):
+    """density [..., 1], color logits [..., 3] at `points` seen along `directions`.  ``gates`` / ``record``:
+    the ten wide layers' ReLU gates in the order block_0, block_1, block_2 (see ``_block``)."""
+    gates = None if gates is None else iter(gates)
     pe_x = positional_encoding(points / cfg["normalize_position"], cfg["position_freqs"], cfg["multiplier"])
     d = directions
     if cfg["normalize_directions"]:
         d = d / d.norm(dim=-1, keepdim=True)
     pe_d = positional_encoding(d, cfg["direction_freqs"], cfg["multiplier"])
-    h = _block(params, BLOCK0, pe_x, cfg)
-    h = _block(params, BLOCK1, _concat(h, pe_x, cfg), cfg)
+    h = _block(params, BLOCK0, pe_x, cfg, gates, record)
+    h = _block(params, BLOCK1, _concat(h, pe_x, cfg), cfg, gates, record)
     density = F.linear(h, params["density.weight"], params["density.bias"])
-    hv = _block(params, BLOCK2, _concat(h, pe_d, cfg), cfg)
+    hv = _block(params, BLOCK2, _concat(h, pe_d, cfg), cfg, gates, record)
     color = F.linear(hv, params["color.weight"], params["color.bias"])
     return density, color
 
@@ -123,13 +131,13 @@ def sample_t(n_rays, near, far, num_samples, u=None):
 
 
 def render_rays(params, cfg, rays_o, rays_d, near, far, num_samples, u=None, noise=None,
-                density_noise_std=0.0, return_stages=False):
+                density_noise_std=0.0, return_stages=False, gates=None, record=None):
     """-> rgb [N, 3].  S samples = S network evaluations (points, not intervals); compositing as
     nerf/model.py:438-469 / :660 on the sample points."""
     n = rays_o.shape[0]
     t = sample_t(n, near, far, num_samples, u)
     points = rays_o[:, None, :] + rays_d[:, None, :] * t[..., None]
-    density, color = field(params, cfg, points, rays_d[:, None, :].expand_as(points))
+    density, color = field(params, cfg, points, rays_d[:, None, :].expand_as(points), gates, record)
     if noise is not None:
         density = density + noise * density_noise_std
     gaps = points[..., 1:, :] - points[..., :-1, :]

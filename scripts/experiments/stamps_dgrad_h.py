@@ -1,0 +1,119 @@
+"""Diagnostic (GPU box): where a wave of the split-precision data gradient (nerf_bwd_data_h_kernel) spends an
+item.  Builds a throw-away copy of csrc/ with s_memtime stamps (scalar-only: s_memtime + s_store_dwordx2, no
+vector register and no vmcnt entry is added, so the counted hand-over waits see the product's queue) and prints,
+per hidden layer, the durations of: LayerNorm backward (pass 1 + 2, dY stores issued) | x_hat loads issued +
+row maximum + f16 split | loop entry -> hand-over 1 | -> 2 | -> 3 (the first that must see the 33 memory
+operations retired) | -> 8 (half) | -> loop end.
+usage: python scripts/experiments/stamps_dgrad_h.py [rays]"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+STAMP_MACRO = r'''
+#define STAMP()                                                                                           \
+    do {                                                                                                  \
+        if (stamp_on && stamp_off < 2040u) {                                                              \
+            uint64_t t_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, %2"           \
+                         : "=&s"(t_) : "s"(stamp_buf), "s"(stamp_off) : "memory");                        \
+            stamp_off += 8u;                                                                              \
+        }                                                                                                 \
+    } while (0)
+struct StampHook {
+    GammaBetaTurn& turn;
+    const bool stamp_on;
+    uint64_t* const stamp_buf;
+    uint32_t& stamp_off;
+    __device__ __forceinline__ void operator()(int t) const {
+        turn(t);
+        if (t == 1 || t == 2 || t == 3 || t == 8) STAMP();
+    }
+};
+'''
+
+
+def patch(src):
+    s = open(src).read()
+    s = s.replace("constexpr int kYoungerL5 = 17, kYoungerHidden = 33;",
+                  "constexpr int kYoungerL5 = 17, kYoungerHidden = 33;" + STAMP_MACRO)
+    head, kern = s.split("__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel", 1)
+    kern, tail = kern.split("// All six layers in ONE launch", 1)
+    kern = kern.replace('''    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+''', '''    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+    // workgroups b and b + gridDim/2 share a CU (round-robin dispatch): stamp WG 0 and its partner
+    const bool stamp_on = (blockIdx.x % (gridDim.x / 2)) == 0;
+    uint64_t* const stamp_buf = (uint64_t*)(ba.dymax + (size_t)kMaxDataGrid * 8) + ((blockIdx.x / (gridDim.x / 2)) * 4 + wave) * 256;
+    uint32_t stamp_off = 0;
+''', 1)
+    kern = kern.replace("            const int64_t sp = tile * 16 + j;\n            f32x4 dout[4];",
+                        "            const int64_t sp = tile * 16 + j;\n            STAMP();\n            f32x4 dout[4];", 1)
+    kern = kern.replace("                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});",
+                        "                STAMP();\n                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});\n                STAMP();")
+    kern = kern.replace("                if (L == 0) break;", "                STAMP();\n                if (L == 0) break;")
+    kern = kern.replace("                layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, TurnHook{turn});",
+                        "                STAMP();\n                layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, StampHook{turn, stamp_on, stamp_buf, stamp_off});\n                STAMP();")
+    kern = kern.replace("    if (threadIdx.x < 8) ba.dymax[", "    asm volatile(\"s_dcache_wb\" ::: \"memory\");\n    if (threadIdx.x < 8) ba.dymax[")
+    s = head + "__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel" + kern + "// All six layers in ONE launch" + tail
+    s = s.replace("(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);",
+                  "(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float) + 8 * 256 * 8;")
+    assert s.count("STAMP()") >= 8
+    open(src, "w").write(s)
+
+
+def main():
+    if "NERF_HIP_LIB" not in os.environ:
+        from nerf_amd import build as B
+        work = tempfile.mkdtemp(prefix="stamps_")
+        csrc = os.path.join(work, "csrc")
+        shutil.copytree(B.CSRC, csrc, ignore=shutil.ignore_patterns("*.so*"))
+        patch(os.path.join(csrc, "nerf_backward.hip"))
+        B.CSRC = csrc
+        out = os.path.join(ROOT, "gpurun_out", "libnerf_hip_stamps.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        B.build(out=out, defines=["NERF_HIP_EXPERIMENT=stamps_dgrad_h"], force=True)
+        sys.exit(subprocess.run([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, NERF_HIP_LIB=out)).returncode)
+    import torch
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    model.train_precision = "f16x3"
+    n, S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
+    o, d, tgt = torch.randn(n, 3, device=dev), torch.randn(n, 3, device=dev), torch.rand(n, 3, device=dev)
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        rgb, _ = model.render_rays(o, d, S, randomly_sample=True, density_noise_std=1.0)
+        ((rgb - tgt.unsqueeze(1)) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    raw = model._scratch_buf.view(torch.int64)[-8 * 256:].cpu().view(8, 256)
+    per_item = 1 + 2 + 4 * 8 + 1
+    # item | L5: loop start, loop end | L = 4..1: LN end, loop start, ho1, ho2, ho3, ho8, loop end (+1: see below) | L0: LN end
+    names = ["item", "L5 start", "L5 end"]
+    for L in (4, 3, 2, 1):
+        names += [f"L{L} LN", f"L{L} split", f"L{L} ho1", f"L{L} ho2", f"L{L} ho3", f"L{L} ho8", f"L{L} end", None]
+    names = [x for x in names if x is not None] + ["L0 LN"]
+    per_item = len(names)
+    for w in (0, 4):
+        ts = [int(v) for v in raw[w] if int(v) != 0]
+        print(f"WG{'AB'[w // 4]} wave 0: {len(ts)} stamps, {len(ts) // per_item} items")
+        for it in range(min(len(ts) // per_item, 6)):
+            seg = ts[it * per_item:(it + 1) * per_item + 1]
+            line = []
+            for i in range(1, len(seg)):
+                nm = names[i] if i < per_item else "next item"
+                line.append(f"{nm} +{(seg[i] - seg[i - 1]) / 100:.2f}")
+            print(f"  item {it} ({(seg[-1] - seg[0]) / 100:.1f} us): " + " | ".join(line))
+    print("(durations in us at the 100 MHz s_memtime tick, each = time since the previous stamp)")
+
+
+if __name__ == "__main__":
+    main()

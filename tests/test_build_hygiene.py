@@ -125,6 +125,30 @@ def test_default_loader_refuses_an_experiment_build(tmp_path):
     assert "LOADED ['probe_build']" in r.stdout, r.stdout + r.stderr
 
 
+def test_loader_refuses_a_library_older_than_its_sources(tmp_path):
+    """The ABI number only changes with the header; a kernel edit does not bump it.  The loader therefore holds
+    the in-tree library to the content hash ``build()`` wrote beside it (nerf_amd/_lib.py: _check_stamp): with a
+    source file changed after the build (here: a copy of csrc/ with one byte appended) it raises instead of
+    running yesterday's kernels."""
+    import shutil
+    from nerf_amd import build as nerf_build
+    nerf_build.build()
+    pkg = tmp_path / "nerf_amd"
+    shutil.copytree(os.path.join(ROOT, "nerf_amd"), pkg, ignore=shutil.ignore_patterns("*.obj", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    code = ("import nerf_amd._lib as L, sys\n"
+            "try:\n    L.lib()\nexcept RuntimeError as e:\n    print('REFUSED', e); sys.exit(0)\n"
+            "print('LOADED')\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path))
+    env.pop("NERF_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert "LOADED" in r.stdout, r.stdout + r.stderr            # an exact copy of the tree loads
+    with open(pkg / "csrc" / "nerf_device.h", "a") as f:
+        f.write("\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert "REFUSED" in r.stdout and "stale" in r.stdout, r.stdout + r.stderr
+
+
 def test_workspace_mirror_matches_the_library():
     from nerf_amd import _lib, build as nerf_build
     import workspace_mirror as W
@@ -133,4 +157,5 @@ def test_workspace_mirror_matches_the_library():
     assert _lib.build_flags() == []
     for n, S in ((1, 2), (3, 17), (5, 9), (130, 64), (256, 100), (4096, 64)):
         assert W.train_layout(n, S)["total"] * 4 == lib.nerf_hip_train_workspace_bytes(n, S)
+        assert W.legacy_train_layout(n, S)["total"] * 4 == lib.nerf_hip_legacy_train_workspace_bytes(n, S)
     assert sorted(W.layer0_feature_order().tolist()) == list(range(96))

@@ -144,3 +144,36 @@ def test_stochastic_render_image_draws_in_the_reference_chunk_order():
                                    noise=torch.cat(noises), density_noise_std=std, return_stages=True)
     ok = st["density"][:, -1, 0].abs() > 1e-5
     assert (img.reshape(-1, 3).cpu() - ref)[ok].abs().max() <= 1e-5
+
+
+def test_deterministic_render_image_leaves_the_generator_where_the_reference_does():
+    """On the deterministic path the reference still draws ``randn([n, S-1, 1])`` once per chunk of its loop and
+    multiplies it by zero (nerf/model.py:652-654, :757-761).  The one-launch ``render_image`` draws nothing but
+    advances torch's device generator by exactly that much (rng="torch"), so the caller's NEXT draw is the one it
+    would get after the reference's call.  B = 2 frames of 5 x 7 in chunks of 16 rays: four full chunks + a tail
+    of 6, the third chunk straddling the frames."""
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    model = NeRF(focal_length=5.6)
+    model.load_state_dict(golden_params(1.0))
+    model = model.to(dev)
+    cam_o = torch.tensor([[0.0, -3.0, 2.6], [2.5, 1.5, 2.0]])
+    cam_r = torch.cat([O.look_at_pose(c.tolist()) for c in cam_o])
+    S, H, W, chunk = 24, 5, 7, 16
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(123)
+    with torch.no_grad():
+        model.render_image(cam_o.to(dev), cam_r.to(dev), H, W, 5.6, S, max_chunk_size=chunk)
+    offset_here, next_here = gen.get_offset(), torch.rand(33, device=dev)
+    # the reference's loop consumes, per chunk, one randn of the chunk's [n, S-1, 1] (and nothing else)
+    torch.manual_seed(123)
+    for n in [chunk] * (2 * H * W // chunk) + [2 * H * W % chunk]:
+        torch.randn(n, S - 1, 1, device=dev)
+    assert gen.get_offset() == offset_here and offset_here > 0
+    assert torch.equal(torch.rand(33, device=dev), next_here)
+    # in-kernel draws (rng="philox") leave torch's generator alone by contract
+    model.rng = "philox"
+    torch.manual_seed(123)
+    with torch.no_grad():
+        model.render_image(cam_o.to(dev), cam_r.to(dev), H, W, 5.6, S, max_chunk_size=chunk)
+    assert gen.get_offset() == 0

@@ -1,18 +1,25 @@
 """Training path of the LEGACY 8 x 256 network of examples/nerf.pth (the network
 BASELINE.json's north_star names).  PARITY UNPINNED like its forward — no reference source exists — so the bar
-is the HIP backward against autograd through oracle/legacy_oracle.py, with the rules of
-tests/test_gpu_backward.py: every one of the 44 gradients within 5e-6 + 8 x (the deviation of the fp32
-oracle's gradients from their fp64 evaluation on that input) of the tensor's largest gradient — the
-gradient is discontinuous in ReLU gates that sit within rounding of zero — and a 32-step training trajectory
-(the notebook's loop: examples/example.ipynb cell 8) against the oracle's CPU run on a scene rendered from the
-reference's own trained weights (fixture G9)."""
+is the HIP backward against autograd through oracle/legacy_oracle.py: every one of the 44 gradients within 1e-4
+of the tensor's largest gradient, on random, freshly initialised and trained weights alike.  The comparison is
+GATE-AWARE: a gradient is discontinuous in every ReLU gate, and an untrained network of this architecture has
+gates within rounding of zero in nearly dead layers (one such gate moves a gradient by percents), so the oracle
+differentiates with the gates the KERNEL used — read from the training workspace it saved (a_hat > shift,
+tests/workspace_mirror.py) — i.e. both sides differentiate the same piecewise-linear function; separately the
+kernel's gates must BE the oracle's own up to a stated handful (<= 1e-5 of them; measured <= 4e-7).  Then a
+32-step training trajectory (the notebook's loop: examples/example.ipynb cell 8) against the oracle's CPU run on a
+scene rendered from the reference's own trained weights (fixture G9)."""
 import numpy as np
 import pytest
 import torch
 
+import workspace_mirror as W
 from conftest import load_golden
 from oracle import legacy_oracle as L
 from oracle import nerf_oracle as O
+
+GRAD_BOUND = 1e-4            # every gradient tensor, relative to its largest element, gate-aware
+GATE_FLIP_BOUND = 1e-5       # fraction of the 10 x 256 ReLU gates per sample that may differ from the oracle's own
 
 CFG = L.default_config()
 
@@ -61,6 +68,20 @@ def oracle_gradients(params, loss_fn, dtype):
     return float(loss.detach()), {k: v.grad.float() for k, v in p.items()}
 
 
+def kernel_gates(model, n_rays, num_samples):
+    """The ten wide layers' ReLU gates [n, S, 256] the training forward of ``model`` just ran with (its saved
+    workspace: ``model.keep_workspace`` must be set)."""
+    return [g.cpu() for g in W.legacy_saved_gates(model.last_workspace, n_rays, num_samples)]
+
+
+def check_gates(own, gates):
+    """The kernel's gates against the oracle's own: they may only differ where y sits within rounding of zero."""
+    flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
+    total = sum(a.numel() for a in gates)
+    assert len(own) == len(gates) == 10 and flips <= GATE_FLIP_BOUND * total, (flips, total)
+    return flips, total
+
+
 def test_parameter_order_is_the_kernels_tensor_order():
     """parameters() order == the pack routine's / the flat gradient's order (nerf_legacy_layout.h), so the
     flat vector aliases every p.grad in optimiser and all-reduce order; 638,468 elements."""
@@ -92,34 +113,36 @@ def test_all_44_gradients_vs_oracle_autograd(weights, n_rays, num_samples):
     noise = torch.randn(n_rays, num_samples, 1, generator=gen)
     w_rgb = torch.randn(n_rays, 3, generator=gen)
 
-    def loss_of(p, cast):
-        rgb = L.render_rays(p, CFG, cast(o), cast(d), near, far, num_samples, u=cast(u), noise=cast(noise),
-                            density_noise_std=0.5)
-        return (rgb * cast(w_rgb)).sum()
-
-    loss_r, ref = oracle_gradients(params, lambda p: loss_of(p, lambda t: t), torch.float32)
-    _, exact = oracle_gradients(params, lambda p: loss_of(p, lambda t: t.double()), torch.float64)
-    noise_floor = max(rel_err(ref[k], exact[k]) for k in ref)
-
     model = make_model(dev, params)
+    model.keep_workspace = True
     rgb = model.render_rays(o.to(dev), d.to(dev), near, far, num_samples, randomly_sample=True, density_noise_std=0.5,
                             u=u.to(dev), noise=noise[..., 0].to(dev))
     assert rgb.requires_grad and rgb.shape == (n_rays, 3)
     loss = (rgb * w_rgb.to(dev)).sum()
     loss.backward()
+    gates = kernel_gates(model, n_rays, num_samples)
+
+    def loss_of(p, gates=None, record=None):
+        out = L.render_rays(p, CFG, o, d, near, far, num_samples, u=u, noise=noise, density_noise_std=0.5,
+                            gates=gates, record=record)
+        return (out * w_rgb).sum()
+
+    own = []
+    loss_r, plain = oracle_gradients(params, lambda p: loss_of(p, record=own), torch.float32)
+    _, ref = oracle_gradients(params, lambda p: loss_of(p, gates=gates), torch.float32)
+    flips, total = check_gates(own, gates)
     assert abs(float(loss.detach()) - loss_r) <= 1e-4 * max(1.0, abs(loss_r))
     worst = 0.0
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == ref[k].shape, k
         e = rel_err(p.grad.cpu(), ref[k])
         worst = max(worst, e)
-        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
-    # (untrained networks of this architecture have samples whose layers are nearly dead — 1/std up to 316 — and a
-    #  single ReLU gate at rounding then moves a gradient by percents, in the oracle's own fp32-vs-fp64 comparison
-    #  as in ours; the trained checkpoint is well conditioned, and there the bound above is tight)
-    if weights == "checkpoint":
-        assert worst <= 1e-3, worst
-    print(f"[{weights} {n_rays}x{num_samples}] worst relative gradient error {worst:.2e} (oracle fp32 vs fp64: {noise_floor:.2e})")
+        assert e <= GRAD_BOUND, (k, e)
+    if flips == 0:                       # same gates: the oracle as it is says the same
+        assert max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()) <= GRAD_BOUND
+    print(f"[{weights} {n_rays}x{num_samples}] worst relative gradient error {worst:.2e}; {flips} of {total} gates differ "
+          f"from the oracle's own (vs the oracle on ITS gates: "
+          f"{max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
 
 
 @pytest.mark.gpu
@@ -274,7 +297,7 @@ def test_training_steps_on_the_checkpoints_scene_track_the_oracle(graph, steps):
 def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameters():
     """The conditioning-free version of the trajectory test: along the oracle's own 16-step training run on the
     same scene, the HIP model is given the oracle's parameters before EVERY step; the loss must agree to 1e-5
-    relative at every step and, every eighth step, all 44 gradients within the rule of the gradient tests."""
+    relative at every step and, every eighth step, all 44 gradients within GRAD_BOUND of the gate-aware oracle."""
     from nerf_amd import trainer as T
     dev = torch.device("cuda:0")
     steps, batch, S, lr, size = 16, 256, 32, 5e-4, 16
@@ -282,6 +305,7 @@ def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameter
     data = T.PixelRayDataset(images[:-1], torch.zeros(5, size, size, dtype=torch.int64, device=dev), poses[:-1], focal)
     params0 = L.init_params(seed=5)
     model = make_model(dev, params0)
+    model.keep_workspace = True
     ref = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
     ref_opt = torch.optim.Adam([ref[k] for k in L.state_dict_keys()], lr=lr)
     gen = torch.Generator().manual_seed(6)
@@ -299,21 +323,22 @@ def test_every_step_of_a_training_run_matches_the_oracle_from_the_same_parameter
         loss.backward()
         o, d, target = b["rays_o"].cpu(), b["rays_d"].cpu(), b["pixels"].cpu()
 
-        def loss_of(p, cast):
-            px = L.render_rays(p, CFG, cast(o), cast(d), 2.0, 6.0, S, u=cast(u), noise=cast(noise), density_noise_std=1.0)
-            return ((px - cast(target)) ** 2).mean()
-
-        ref_loss = loss_of(ref, lambda t: t)
+        ref_px = L.render_rays(ref, CFG, o, d, 2.0, 6.0, S, u=u, noise=noise, density_noise_std=1.0)
+        ref_loss = ((ref_px - target) ** 2).mean()
         ref_opt.zero_grad()
         ref_loss.backward()
         assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * float(ref_loss.detach()), step
         if step % 8 == 0:
-            _, exact = oracle_gradients({k: v.detach() for k, v in ref.items()}, lambda p: loss_of(p, lambda t: t.double()),
-                                        torch.float64)
-            noise_floor = max(rel_err(ref[k].grad, exact[k]) for k in ref)
+            gates = kernel_gates(model, batch, S)
+
+            def gated_loss(p):
+                px = L.render_rays(p, CFG, o, d, 2.0, 6.0, S, u=u, noise=noise, density_noise_std=1.0, gates=gates)
+                return ((px - target) ** 2).mean()
+
+            _, gated = oracle_gradients({k: v.detach() for k, v in ref.items()}, gated_loss, torch.float32)
             for k, p in model.named_parameters():
-                e = rel_err(p.grad.cpu(), ref[k].grad)
-                assert e <= 5e-6 + 8 * noise_floor, (step, k, e, noise_floor)
+                e = rel_err(p.grad.cpu(), gated[k])
+                assert e <= GRAD_BOUND, (step, k, e)
         ref_opt.step()
 
 

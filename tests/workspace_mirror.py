@@ -82,3 +82,59 @@ def saved_rstd(workspace, layer, n_rays, num_samples):
     """1 / sqrt(var + eps) of hidden layer ``layer``: [n_rays, S-1]."""
     lay = train_layout(n_rays, num_samples)
     return _rows(workspace, lay, lay["rstd"][layer], 1, n_rays, num_samples)[..., 0]
+
+
+# ---- the legacy 8 x 256 network's workspace (nerf_amd/csrc/nerf_legacy_layout.h: LegacyTrainLayout) ----------
+LEGACY_WIDE, LEGACY_ENC_PAD = 10, 64
+
+
+def legacy_chunks_of(num_samples):
+    return (num_samples + SAMPLES_PER_WAVE - 1) // SAMPLES_PER_WAVE      # S samples = S evaluations here
+
+
+def legacy_train_layout(n_rays, num_samples):
+    """Offsets (in floats) like ``make_legacy_train_layout``: encodings, then per wide layer a_hat rows, 1/std and
+    the gate threshold ``shift``, then the head outputs and the compositing state.  (dY rows are the backward's.)"""
+    chunks = legacy_chunks_of(num_samples)
+    mp = (n_rays + 3) // 4 * 4 * chunks * 16
+    lay, off = {"mp": mp, "chunks": chunks}, 0
+    for name in ("pos", "dir"):
+        lay[name] = off
+        off += mp * LEGACY_ENC_PAD
+    for name, width in (("xhat", HIDDEN), ("rstd", 1), ("shift", 1)):
+        lay[name] = []
+        for _ in range(LEGACY_WIDE):
+            lay[name].append(off)
+            off += mp * width
+    lay["out"] = off
+    off += mp * OUT_PAD
+    lay["comp"] = off
+    off += mp * 4
+    lay["total"] = off
+    return lay
+
+
+def _legacy_rows(workspace, lay, offset, width, n_rays, num_samples):
+    chunks, mp = lay["chunks"], lay["mp"]
+    rows = workspace[offset:offset + mp * width].view(mp // (chunks * 16), chunks * 16, width)
+    return rows[:n_rays, :num_samples]
+
+
+def legacy_saved_layer(workspace, layer, n_rays, num_samples):
+    """(a_hat [n, S, 256], 1/std [n, S], shift [n, S]) of wide layer ``layer`` (0..3 block_0, 4..7 block_1,
+    8..9 block_2): a_hat = (relu(y) - mean) / std, ``shift`` = the a_hat of a closed gate."""
+    lay = legacy_train_layout(n_rays, num_samples)
+    assert workspace.numel() == lay["total"], (workspace.numel(), lay["total"])
+    return (_legacy_rows(workspace, lay, lay["xhat"][layer], HIDDEN, n_rays, num_samples),
+            _legacy_rows(workspace, lay, lay["rstd"][layer], 1, n_rays, num_samples)[..., 0],
+            _legacy_rows(workspace, lay, lay["shift"][layer], 1, n_rays, num_samples)[..., 0])
+
+
+def legacy_saved_gates(workspace, n_rays, num_samples):
+    """The ReLU gates the kernels differentiate through, one bool [n, S, 256] per wide layer: y > 0 <=> a_hat >
+    shift (exact: the forward moves an open gate whose a_hat rounds onto ``shift`` one ulp up)."""
+    gates = []
+    for layer in range(LEGACY_WIDE):
+        xhat, _, shift = legacy_saved_layer(workspace, layer, n_rays, num_samples)
+        gates.append(xhat > shift[..., None])
+    return gates
