@@ -250,6 +250,130 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
             "ray_samples_per_s_graph": rays * samples / t_graph}
 
 
+def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, samples=64, train_precision="f16x3"):
+    """BASELINE config 5 as the N > 1 measurement: ONE 4096-ray batch per step, data-parallel over `world` ranks
+    (rays rank * 4096 / world ... of the same batch on every rank), each rank running training forward + HIP backward
+    on its share, then ONE in-place all-reduce of the flat 304,438-float gradient (nerf_amd/parallel.py), then the
+    one-launch Adam redundantly on every rank; in-kernel Philox draws (rank folded into the key).  Reference step:
+    train_conditional_nerf.py:115-135.  Measured twice: launch by launch with the collective bracketed by events on
+    the launch stream, and as ONE HIP-graph replay per step — with RCCL the collective and the optimiser are inside
+    the captured region (they are stream-ordered kernels), over gloo (a rehearsal) they stay outside and the entry
+    says so.  Afterwards every rank's parameters must be bit-identical (checksum all-gather)."""
+    import torch.distributed as dist
+    from nerf_amd import NeRF
+    from nerf_amd.loss import mse_and_grad
+    from nerf_amd.optim import Adam
+    from nerf_amd.parallel import FlatGradientAllReduce, broadcast_parameters, shard_items
+    torch.manual_seed(0)
+    model = NeRF().to(dev)
+    model.train_precision = train_precision
+    model.rng = "philox"
+    broadcast_parameters(model)
+    begin, end = shard_items(rays, rank, world)
+    gen = torch.Generator(device=dev).manual_seed(20260)             # the same global batch on every rank
+    o_all = torch.randn(rays, 3, generator=gen, device=dev)
+    d_all = torch.randn(rays, 3, generator=gen, device=dev)
+    t_all = torch.rand(rays, 3, generator=gen, device=dev)
+    o, d, target = (t[begin:end].contiguous() for t in (o_all, d_all, t_all))
+    n, weight = end - begin, (end - begin) / float(rays)
+    opt = Adam(model.parameters(), lr=1e-4)
+    reduce = FlatGradientAllReduce(model.parameters())
+    in_graph = backend == "nccl"
+    marks = []
+
+    def local_part():
+        pixels, _ = model.render_rays(o, d, samples, randomly_sample=True, density_noise_std=1.0)
+        loss, grad = mse_and_grad(pixels, target)
+        pixels.backward(grad)
+
+    def collective_part(timed=False):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        reduce(model.last_flat_grad, weight)
+        if timed:
+            e1.record()
+            marks.append((e0, e1))
+        opt.step()
+
+    def eager(timed=False):
+        opt.zero_grad(set_to_none=True)
+        local_part()
+        collective_part(timed)
+
+    def timed_loop(fn):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend != "gloo" else "cpu")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()) / steps
+
+    for _ in range(max(warmup, 3)):
+        eager()
+    t_eager = timed_loop(lambda: eager(True))
+    allreduce_ms = sum(a.elapsed_time(b) for a, b in marks) / max(len(marks), 1)
+    assert reduce.in_place_calls > 0, "the all-reduce must run in place on the backward's flat gradient"
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                                     # autograd's accumulation nodes on the capture stream
+        for _ in range(2):
+            eager()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    fence()
+    graph, captured, why = torch.cuda.CUDAGraph(), in_graph, None
+    opt.zero_grad(set_to_none=True)
+    try:
+        with torch.cuda.graph(graph, stream=side):
+            local_part()
+            if in_graph:
+                collective_part()
+    except Exception as exc:                                          # (RCCL capture refused: fall back, and say so)
+        if not in_graph:
+            raise
+        captured, why = False, f"{type(exc).__name__}: {exc}"[:200]
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph, stream=side):
+            local_part()
+    static_flat = model.last_flat_grad
+
+    def replay():
+        graph.replay()
+        if not captured:
+            reduce(static_flat, weight)
+            opt.step()
+
+    replay()
+    t_graph = timed_loop(replay)
+    # replicas: identical parameters on every rank after all those steps (sum of the parameters' bit patterns)
+    bits = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).view(torch.int32).to(torch.int64)
+    check = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev)).sum()])
+    if backend == "gloo":
+        check = check.cpu()
+    gathered = [torch.empty_like(check) for _ in range(world)]
+    dist.all_gather(gathered, check)
+    identical = all(torch.equal(g, gathered[0]) for g in gathered)
+    finite = bool(torch.isfinite(torch.cat([p.detach().reshape(-1) for p in model.parameters()])).all())
+    return {"workload": f"BASELINE config 5: {rays}-ray batches x {samples} samples, data-parallel over {world} ranks "
+                        f"({n} rays on rank 0), training forward + HIP backward + one in-place all-reduce of the flat "
+                        f"{reduce.numel}-float gradient + one-launch Adam on every rank; {train_precision}; in-kernel Philox draws",
+            "rays_per_rank": n, "global_batch": rays, "steps": steps,
+            "rendezvous_backend": backend, "collective": "all_reduce(SUM) of one flat fp32 buffer, in place",
+            "gradient_bytes": reduce.numel * 4,
+            "eager": {"ms_per_step": t_eager * 1e3, "allreduce_ms": allreduce_ms,
+                      "ray_samples_per_s": rays * samples / t_eager},
+            "graph": {"ms_per_step": t_graph * 1e3, "ray_samples_per_s": rays * samples / t_graph,
+                      "collective_and_optimiser_in_graph": captured,
+                      **({"capture_fallback": why} if why else {}),
+                      **({} if in_graph else {"note": "gloo is a host-side collective: it and Adam run after the replay"})},
+            "replicas_identical": identical, "parameters_finite": finite}
+
+
 def legacy_workload_timing(dev, steps=3, warmup=1):
     """Second workload: the same 800x800x128 frame through the LEGACY 8 x 256 network of the
     reference's examples/nerf.pth (sin/cos encoding, skip trunk, view branch; 1,261,568 FLOP per sample,
@@ -564,9 +688,11 @@ def main():
                 "rays_per_rank": rays_rank, "value": total_rays * SAMPLES * steps / float(t.item())}
 
     m = measure(args.scaling, args.steps, args.warmup)
-    weak = None
+    weak = dp = None
     if distributed and args.scaling == "strong":
         weak = measure("weak", args.steps, args.warmup)
+    if distributed:
+        dp = train_step_dp(dev, rank, world, backend, max(args.steps, 10), args.warmup, fence)
 
     if rank == 0:
         line = {
@@ -597,6 +723,8 @@ def main():
             "roofline": roofline(args.precision, m["rays_per_rank"], m["kernel_ms"], m["launches"],
                                  world == 1),
         }
+        if dp is not None:
+            line["train_step_dp"] = dp
         if weak is not None:
             line["weak_scaling"] = {"value": weak["value"], "unit": "ray-samples/s",
                                     "ms_per_step": weak["elapsed"] / args.steps * 1e3,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 5
+#define NERF_HIP_ABI_VERSION 6
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -98,6 +98,9 @@ typedef struct NerfHipRenderArgs {
                                    bit1: draw noise in-kernel when noise==NULL            */
     uint64_t rng_seed, rng_offset;  /* Philox key = seed ^ offset: a distinct offset per launch (and
                                    per data-parallel rank) gives independent draws            */
+    const uint64_t* rng_counter;    /* NULL, or a DEVICE word added to rng_offset when the kernel runs: a launch
+                                   captured in a HIP graph replays its argument block, so what must differ from
+                                   replay to replay lives in device memory; nerf_hip_rng_advance() moves it */
     /* --- network */
     float base_radius_sq;       /* (1/(sqrt(3)*focal))^2 with the CONSTRUCTOR focal (:546) */
     const float* packed;        /* image written by nerf_hip_pack_weights                  */
@@ -268,6 +271,12 @@ typedef struct NerfHipAdamArgs {
 } NerfHipAdamArgs;
 
 int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream);
+
+/* *counter += delta as one tiny launch on `stream` (stream-ordered behind the launches that read the word through
+ * NerfHipRenderArgs.rng_counter, in front of the next ones; capturable: a replayed training step draws new
+ * samples).  No reference counterpart: the reference draws from torch's global generator (nerf/model.py:432,
+ * :652), whose state a captured region advances the same way (a device-side offset). */
+int nerf_hip_rng_advance(uint64_t* counter, uint64_t delta, void* stream);
 
 /* The loss of those loops and its gradient in one launch: loss = mean((pred - target[:, None, :]) ** 2) over
  * pred [n_rays, stages, 3] and target [n_rays, 3] (train_conditional_nerf.py:132: `((pixels -

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -28,7 +28,7 @@ class RenderArgs(ctypes.Structure):
         ("t_values", _f32p), ("u", _f32p), ("noise", _f32p),
         ("density_noise_std", ctypes.c_float),
         ("rng_mode", ctypes.c_int32),
-        ("rng_seed", ctypes.c_uint64), ("rng_offset", ctypes.c_uint64),
+        ("rng_seed", ctypes.c_uint64), ("rng_offset", ctypes.c_uint64), ("rng_counter", _f32p),
         ("base_radius_sq", ctypes.c_float),
         ("packed", _f32p),
         ("rgb", _f32p), ("seg", _f32p),
@@ -162,6 +162,8 @@ def lib():
     handle.nerf_hip_legacy_render_backward.argtypes = [ctypes.POINTER(LegacyBackwardArgs), ctypes.c_void_p]
     handle.nerf_hip_adam_step.restype = ctypes.c_int
     handle.nerf_hip_adam_step.argtypes = [ctypes.POINTER(AdamArgs), ctypes.c_void_p]
+    handle.nerf_hip_rng_advance.restype = ctypes.c_int
+    handle.nerf_hip_rng_advance.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
     handle.nerf_hip_mse_loss.restype = ctypes.c_int
     handle.nerf_hip_mse_loss.argtypes = [ctypes.POINTER(MseArgs), ctypes.c_void_p]
     handle.nerf_hip_timing.restype = ctypes.c_int
@@ -190,6 +192,7 @@ EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "n
            "nerf_hip_legacy_pack_weights", "nerf_hip_legacy_render_forward",
            "nerf_hip_legacy_train_workspace_bytes", "nerf_hip_legacy_grad_elements",
            "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_adam_step", "nerf_hip_mse_loss",
+           "nerf_hip_rng_advance",
            "nerf_hip_timing",
            "nerf_hip_timing_read")
 

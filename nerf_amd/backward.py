@@ -23,10 +23,11 @@ class RenderRaysFunction(torch.autograd.Function):
         ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
         workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
         rng_state = model._next_philox_state() if rng_mode else None
+        rng_counter = model._philox_device_counter(device) if rng_mode else None     # (graph replay: new draws)
         rgb, seg, _, _, weights = model._launch(n_rays, num_samples, device, rays_o=rays_o,
                                                 rays_d=rays_d, u=u, noise=noise,
                                                 density_noise_std=density_noise_std, rng_mode=rng_mode,
-                                                rng_state=rng_state, t_values=t_values,
+                                                rng_state=rng_state, rng_counter=rng_counter, t_values=t_values,
                                                 want_weights=want_weights, train_workspace=workspace)
         if weights is None:
             weights = rgb.new_empty(0)

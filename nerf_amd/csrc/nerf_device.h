@@ -589,6 +589,12 @@ __device__ __forceinline__ Ray load_ray(const NerfHipRenderArgs& a, int64_t loca
 }
 
 // Fencepost s of a ray (nerf/model.py:414-435), s clamped to the table.
+// The launch's Philox offset: the argument block's, plus the device-resident word a graph-replayed launch is
+// told apart by (include/nerf_hip.h: rng_counter).  A uniform address: one scalar load, only on drawing paths.
+__device__ __forceinline__ uint64_t rng_offset_of(const NerfHipRenderArgs& a) {
+    return a.rng_counter != nullptr ? a.rng_offset + *a.rng_counter : a.rng_offset;
+}
+
 __device__ __forceinline__ float fencepost(const NerfHipRenderArgs& a, int64_t local, int s) {
 #pragma clang fp contract(off)
     const int S = a.num_samples;
@@ -601,7 +607,7 @@ __device__ __forceinline__ float fencepost(const NerfHipRenderArgs& a, int64_t l
         const float lower = s == 0 ? cur : 0.5f * (cur + a.t_table[s - 1]);
         const float upper = s == S - 1 ? cur : 0.5f * (a.t_table[s + 1] + cur);
         const float uu = a.u != nullptr ? a.u[local * S + s]
-                                        : nerf_rng::uniform(a.rng_seed, a.rng_offset,
+                                        : nerf_rng::uniform(a.rng_seed, rng_offset_of(a),
                                                             (uint64_t)(a.ray_begin + local), (uint32_t)s, 0u);
         t = lower + (upper - lower) * uu;
     }
@@ -643,7 +649,7 @@ __device__ __forceinline__ void fencepost_run(const NerfHipRenderArgs& a, int64_
     } else {
 #pragma unroll
         for (int k = 0; k < N; ++k)
-            uu[k] = nerf_rng::uniform(a.rng_seed, a.rng_offset, (uint64_t)(a.ray_begin + local), (uint32_t)at[k], 0u);
+            uu[k] = nerf_rng::uniform(a.rng_seed, rng_offset_of(a), (uint64_t)(a.ray_begin + local), (uint32_t)at[k], 0u);
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -771,7 +777,7 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
     if (a.noise != nullptr) {
         if (ok) dens = dens + a.noise[local * P + s] * a.density_noise_std;
     } else if (a.rng_mode & 2) {
-        dens = dens + nerf_rng::normal(a.rng_seed, a.rng_offset, (uint64_t)(a.ray_begin + local),
+        dens = dens + nerf_rng::normal(a.rng_seed, rng_offset_of(a), (uint64_t)(a.ray_begin + local),
                                        (uint32_t)s, 1u) * a.density_noise_std;
     }
     const float alpha = ok ? expf(-__builtin_fmaxf(dens, 0.f) * dist) : 1.0f;

@@ -244,6 +244,14 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     return nerf_common::check_hip(hipGetLastError(), "adam_step launch");
 }
 
+__global__ void nerf_rng_advance_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
+
+extern "C" int nerf_hip_rng_advance(uint64_t* counter, uint64_t delta, void* stream) {
+    if (counter == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "rng_advance: null counter");
+    hipLaunchKernelGGL(nerf_rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    return nerf_common::check_hip(hipGetLastError(), "rng_advance launch");
+}
+
 extern "C" int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null args");
     const NerfHipMseArgs& a = *args;

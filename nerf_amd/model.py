@@ -212,6 +212,17 @@ class NeRF(nn.Module):
         self._philox_calls += 1
         return state
 
+    def _philox_device_counter(self, device):
+        """The device-resident half of the launch counter (include/nerf_hip.h: rng_counter): every launch that
+        draws in-kernel adds this word to its Philox offset and is followed by a one-thread launch that
+        increments it.  Eagerly that only doubles what ``_philox_calls`` already does; inside a HIP-graph
+        replay — which repeats its argument block, the host-side offset included — it is what gives every
+        replayed step new draws (``Trainer(graph=True, rng="philox")``)."""
+        cur = getattr(self, "_philox_counter", None)
+        if cur is None or cur.device != device:
+            self._philox_counter = cur = torch.zeros(1, dtype=torch.int64, device=device)
+        return cur
+
     def sample_along_rays(self, rays_o, rays_d, num_samples, states_x=None, states_d=None,
                           randomly_sample=True):
         """Fenceposts [..., S] along each ray, log-spaced, optionally stratified
@@ -329,8 +340,8 @@ class NeRF(nn.Module):
 
     def _fill_args(self, args, n_rays, num_samples, device, *, rays_o=None, rays_d=None,
                    cameras=None, ray_begin=0, t_values=None, u=None, noise=None,
-                   density_noise_std=0.0, rng_mode=0, rng_state=None, packed=None, rgb=None, seg=None,
-                   mean=None, cov=None, raw=None, weights=None, train_workspace=None, out_t=None,
+                   density_noise_std=0.0, rng_mode=0, rng_state=None, rng_counter=None, packed=None, rgb=None,
+                   seg=None, mean=None, cov=None, raw=None, weights=None, train_workspace=None, out_t=None,
                    precision=None):
         """Fill a NerfHipRenderArgs block (include/nerf_hip.h) from tensors.  ``precision``: the
         backward passes the arithmetic its forward ran with (already range-checked)."""
@@ -347,6 +358,7 @@ class NeRF(nn.Module):
         args.rng_mode = int(rng_mode)
         if rng_mode:
             args.rng_seed, args.rng_offset = rng_state
+            args.rng_counter = _lib.ptr(rng_counter)
         r_dot = 1.0 / (math.sqrt(3.0) * self.focal_length)          # nerf/model.py:546
         args.base_radius_sq = r_dot ** 2
         args.packed = _lib.ptr(packed)
@@ -374,8 +386,12 @@ class NeRF(nn.Module):
 
     def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
                 ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
-                want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None,
+                want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None, rng_counter=None,
                 train_workspace=None, want_weights=False, cov=None, out_t=None):
+        """``rng_state`` None with ``rng_mode``: the module's own launch sequence (host counter + device counter,
+        advanced behind the launch); an explicit state is used as it is (reproducible draws), plus
+        ``rng_counter`` if the caller passes one (the training forward: its own sequence state, kept for the
+        backward's argument block)."""
         lib = _lib.lib()
         packed = self.packed_parameters(fresh=train_workspace is not None)
         P = num_samples - 1
@@ -394,16 +410,21 @@ class NeRF(nn.Module):
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         if rng_mode and rng_state is None:
             rng_state = self._next_philox_state()
+            rng_counter = self._philox_device_counter(device)
         args = _lib.RenderArgs()
         self._fill_args(args, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
                         cameras=cameras, ray_begin=ray_begin, t_values=t_values, u=u, noise=noise,
                         density_noise_std=density_noise_std, rng_mode=rng_mode, rng_state=rng_state,
+                        rng_counter=rng_counter if rng_mode else None,
                         packed=packed, rgb=rgb, seg=seg, mean=mean, cov=cov, raw=raw, weights=weights,
                         train_workspace=train_workspace, out_t=out_t)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.nerf_hip_render_forward(ctypes.byref(args), ctypes.c_void_p(stream)),
                        "nerf_hip_render_forward")
+            if rng_mode and rng_counter is not None:
+                _lib.check(lib.nerf_hip_rng_advance(_lib.ptr(rng_counter), 1, ctypes.c_void_p(stream)),
+                           "nerf_hip_rng_advance")
         if self.segmentation_outputs == 0:
             seg = seg_given                              # the caller's empty [n, 0] tensor (or None)
         return rgb, seg, mean, raw, weights

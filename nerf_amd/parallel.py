@@ -90,9 +90,11 @@ class FlatGradientAllReduce:
         weight = 1.0 / world if weight is None else float(weight)
         if self._aliases(flat):
             self.in_place_calls += 1
-            if world > 1:
+            # (also with ONE rank: the callers only come here when a process group exists, and a single-rank RCCL
+            #  group is how the captured-collective path is exercised on a one-GPU box)
+            if weight != 1.0:
                 flat.mul_(weight)
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return flat
         ref = self.params[0]
         if self._flat is None or self._flat.device != ref.device:
@@ -105,9 +107,9 @@ class FlatGradientAllReduce:
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        if world > 1:
+        if weight != 1.0:
             flat.mul_(weight)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
         for p in self.params:
             n = p.numel()

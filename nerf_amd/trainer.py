@@ -132,11 +132,14 @@ class Trainer:
         self._stale_grads = False
         begin, end = parallel.shard_items(batch_size, self.rank, self.world)
         self._full_share = end - begin                    # rays of a full global batch that land on this rank
-        if self.use_graph:
-            if rng != "torch":
-                raise ValueError("graph=True needs rng='torch': the in-kernel Philox offset is a launch "
-                                 "argument, a replayed launch would repeat its draws")
+        if self.use_graph and rng == "torch":
             torch.cuda.manual_seed(seed + 7919 * (self.rank + 1))      # draws come from the default generator
+        # (rng="philox" under graph replay: the launch's Philox offset has a device-resident part that a captured
+        #  one-thread launch advances, include/nerf_hip.h: rng_counter — every replay draws new samples)
+        # With RCCL (backend "nccl") the collective is a stream-ordered kernel like any other and is captured
+        # with the step: scale, all-reduce, Adam all replay from the one graph.  Over gloo (CPU rendezvous: tests,
+        # rehearsals) it is a host-side operation and stays outside the captured region, as does the optimiser.
+        self.collective_in_graph = bool(self.distributed and self.use_graph and "nccl" in str(dist.get_backend()))
         # the reference's optimiser (train_conditional_nerf.py:106-107: Adam, default betas / eps) as one launch
         # over all parameter tensors (nerf_amd/optim.py; graph-capturable by construction: its step count lives on
         # the device); torch's own on the CPU
@@ -199,11 +202,15 @@ class Trainer:
     # ---- HIP-graph path ---------------------------------------------------------------------------
     def _graph_body(self, o, d, pix):
         n, dev = o.shape[0], o.device
-        u, noise = self._draw(n, dev, None)               # graph-safe default generator
-        self.last_draws = (u, noise)                      # (static tensors of the graph once captured)
+        u = noise = None
+        if self.model.rng == "torch":
+            u, noise = self._draw(n, dev, None)           # graph-safe default generator
+        self.last_draws = (u, noise)                      # (static tensors of the graph once captured; None: Philox)
         pixels = self._render(o, d, u, noise)
         loss = self._loss_backward(pixels, pix)
-        if not self.distributed:
+        if self.collective_in_graph:                      # full-size batches only: the share is a constant
+            self.reduce(self.model.last_flat_grad, n / float(self.batch_size))
+        if not self.distributed or self.collective_in_graph:
             self.optimizer.step()
         return loss
 
@@ -228,7 +235,7 @@ class Trainer:
             with torch.cuda.stream(self._side):
                 self.optimizer.zero_grad(set_to_none=True)
                 loss = self._graph_body(batch["rays_o"], batch["rays_d"], batch["pixels"])
-                if self.distributed:
+                if self.distributed and not self.collective_in_graph:
                     self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
                     self.optimizer.step()
             torch.cuda.current_stream().wait_stream(self._side)
@@ -251,7 +258,7 @@ class Trainer:
                 p.grad = g
             self.model.last_flat_grad = self._static_flat
             self._stale_grads = False
-        if self.distributed:
+        if self.distributed and not self.collective_in_graph:
             self.reduce(self._static_flat, n / max(int(batch.get("global_n", n * self.world)), 1))
             self.optimizer.step()
         if getattr(self.model, "train_precision", "fp32") == "f16x3" and self.iteration % 64 == 0:

@@ -37,8 +37,28 @@ struct StampHook {
 '''
 
 
-def patch(src):
+VARIANTS = {
+    # timing-only variants (wrong results): what the phases wait for
+    "nostores": [("        *(f32x4*)(dy_row + T * 16) = dy;", "        if (kScaled) asm volatile(\"\" :: \"v\"(dy)); else *(f32x4*)(dy_row + T * 16) = dy;")],
+    "noloads": [("                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);\n                rstd = ws[ba.L.rstd[L - 1] + sp];",
+                 "                for (int T = 0; T < 16; ++T) { xh[T] = f32x4{0.5f, -0.25f, 0.125f, 1.0f}; asm volatile(\"\" : \"+v\"(xh[T])); }\n                rstd = 1.0f; asm volatile(\"\" : \"+v\"(rstd));")],
+    "nonote": [("                note_max(wmax + L, amax, lane);", "")],
+}
+
+
+def patch(src, variant=None):
     s = open(src).read()
+    if variant:
+        common = os.path.join(os.path.dirname(src), "nerf_backward_common.h")
+        c = open(common).read()
+        for name in variant.split("+"):
+            for old, new in VARIANTS[name]:
+                if old in s:
+                    s = s.replace(old, new)
+                else:
+                    assert old in c, (name, old)
+                    c = c.replace(old, new)
+        open(common, "w").write(c)
     s = s.replace("constexpr int kYoungerL5 = 17, kYoungerHidden = 33;",
                   "constexpr int kYoungerL5 = 17, kYoungerHidden = 33;" + STAMP_MACRO)
     head, kern = s.split("__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel", 1)
@@ -66,6 +86,9 @@ def patch(src):
     s = s.replace("(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);",
                   "(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float) + 8 * 256 * 8;")
     assert s.count("STAMP()") >= 8
+    if variant and ("noloads" in variant or "nostores" in variant):
+        n = 33 - (17 if "noloads" in variant else 0) - (16 if "nostores" in variant else 0)
+        s = s.replace("kYoungerHidden = 33;", f"kYoungerHidden = {n};")
     open(src, "w").write(s)
 
 
@@ -75,9 +98,10 @@ def main():
         work = tempfile.mkdtemp(prefix="stamps_")
         csrc = os.path.join(work, "csrc")
         shutil.copytree(B.CSRC, csrc, ignore=shutil.ignore_patterns("*.so*"))
-        patch(os.path.join(csrc, "nerf_backward.hip"))
+        variant = os.environ.get("STAMP_VARIANT") or None
+        patch(os.path.join(csrc, "nerf_backward.hip"), variant)
         B.CSRC = csrc
-        out = os.path.join(ROOT, "gpurun_out", "libnerf_hip_stamps.so")
+        out = os.path.join(ROOT, "gpurun_out", f"libnerf_hip_stamps_{variant or 'base'}.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
         B.build(out=out, defines=["NERF_HIP_EXPERIMENT=stamps_dgrad_h"], force=True)
         sys.exit(subprocess.run([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, NERF_HIP_LIB=out)).returncode)
@@ -102,17 +126,25 @@ def main():
         names += [f"L{L} LN", f"L{L} split", f"L{L} ho1", f"L{L} ho2", f"L{L} ho3", f"L{L} ho8", f"L{L} end", None]
     names = [x for x in names if x is not None] + ["L0 LN"]
     per_item = len(names)
-    for w in (0, 4):
+    import statistics
+    phase = {}
+    items = []
+    for w in range(8):
         ts = [int(v) for v in raw[w] if int(v) != 0]
-        print(f"WG{'AB'[w // 4]} wave 0: {len(ts)} stamps, {len(ts) // per_item} items")
-        for it in range(min(len(ts) // per_item, 6)):
+        for it in range(len(ts) // per_item - 1):
             seg = ts[it * per_item:(it + 1) * per_item + 1]
-            line = []
+            items.append(seg[-1] - seg[0])
             for i in range(1, len(seg)):
                 nm = names[i] if i < per_item else "next item"
-                line.append(f"{nm} +{(seg[i] - seg[i - 1]) / 100:.2f}")
-            print(f"  item {it} ({(seg[-1] - seg[0]) / 100:.1f} us): " + " | ".join(line))
-    print("(durations in us at the 100 MHz s_memtime tick, each = time since the previous stamp)")
+                key = nm.split(" ", 1)[1] if nm[0] == "L" and nm[1] in "1234" else nm
+                phase.setdefault(key, []).append(seg[i] - seg[i - 1])
+    print(f"variant {os.environ.get('STAMP_VARIANT') or 'base'}: {len(items)} items of 8 waves (2 workgroups of one CU); "
+          f"median item {statistics.median(items):.0f} cycles")
+    for key in ("LN", "split", "ho1", "ho2", "ho3", "ho8", "end", "L5 start", "L5 end", "L0 LN", "next item"):
+        v = phase.get(key, [0])
+        print(f"  {key:>9}: median {statistics.median(v):7.0f}  min {min(v):7.0f}  max {max(v):7.0f} cycles")
+    print("(s_memtime ticks = shader cycles; hidden layers L4..L1 pooled: LN = LayerNorm backward incl. the 16 dY stores;"
+          " split = 17 x_hat loads issued + row maximum + f16 split; ho1/2/3/8 = hand-over of stage 1/2/3/8; end = loop end)")
 
 
 if __name__ == "__main__":

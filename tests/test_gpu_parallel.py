@@ -214,3 +214,59 @@ def test_the_drivers_multi_gpu_bench_command_runs_as_a_rehearsal(tmp_path):
     # two ranks time-share one GPU: the frame takes about as long as on one rank, never half
     assert 0.5 * 2.2e8 <= line["value"] <= 1.2 * 2.3e8
     assert line["weak_scaling"]["frames"] == 2 and line["weak_scaling"]["value"] > 0.5 * 2.2e8
+    # BASELINE config 5 in the N > 1 line: the data-parallel training step with its collective
+    dp = line["train_step_dp"]
+    assert dp["rendezvous_backend"] == "gloo" and dp["rays_per_rank"] == 2048 and dp["global_batch"] == 4096
+    assert dp["gradient_bytes"] == 304438 * 4 and dp["replicas_identical"] is True and dp["parameters_finite"] is True
+    assert dp["eager"]["ms_per_step"] > 0 and dp["eager"]["allreduce_ms"] > 0
+    assert dp["graph"]["ms_per_step"] > 0 and dp["graph"]["collective_and_optimiser_in_graph"] is False   # gloo: outside
+
+
+def _rccl_single_rank_worker(rank, world, port, out_dir):
+    """ONE rank on RCCL (backend "nccl"): the only form of the RCCL path a one-GPU box can run.  The collective is
+    then a (trivial) stream-ordered RCCL launch — what matters here is that it, the scale in front of it and the
+    one-launch Adam behind it are CAPTURED in the step's HIP graph and replayed, and that in-kernel Philox draws
+    differ from replay to replay (device-resident launch counter)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import bench
+        from nerf_amd import trainer as T
+
+        def fence():
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        dp = bench.train_step_dp(dev, 0, 1, "nccl", steps=4, warmup=1, fence=fence, rays=512)
+        images, poses, focal = T.synthetic_scene(num_views=4, size=12, num_samples=24, device=dev)
+        run = T.Trainer(images, poses, focal, batch_size=128, learning_rate=5e-4, num_samples_per_ray=24,
+                        density_noise_std=0.5, log_interval=10 ** 9, seed=3, graph=True, rng="philox")
+        assert run.distributed and run.collective_in_graph
+        before = [p.detach().clone() for p in run.model.parameters()]
+        losses = []
+        gen = torch.Generator().manual_seed(5)
+        for _ in range(14):                                        # 5 eager warm-up steps, capture, 8 replays
+            idx = torch.randint(0, len(run.dataset), (128,), generator=gen)
+            run.iteration += 1
+            losses.append(float(run.train_step(run.dataset.gather(idx.to(dev)))))
+        counter = int(run.model._philox_counter.item())
+        moved = any(not torch.equal(a, b) for a, b in zip(before, run.model.parameters()))
+        torch.save(dict(dp=dp, losses=losses, counter=counter, moved=moved, captured=run._graph is not None),
+                   os.path.join(out_dir, "rccl1.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_group_captures_collective_and_optimiser_in_the_step_graph(tmp_path):
+    mp.spawn(_rccl_single_rank_worker, args=(1, free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(os.path.join(tmp_path, "rccl1.pt"), weights_only=False)
+    dp = out["dp"]
+    assert dp["rendezvous_backend"] == "nccl" and dp["replicas_identical"] and dp["parameters_finite"]
+    assert dp["graph"]["collective_and_optimiser_in_graph"] is True, dp["graph"]
+    assert dp["graph"]["ms_per_step"] > 0 and dp["eager"]["allreduce_ms"] > 0
+    assert out["captured"] and out["moved"] and all(l == l and l < 10 for l in out["losses"])
+    assert out["counter"] == 14                                    # one device-side advance per training forward,
+                                                                   # replayed ones included: every replay drew anew
