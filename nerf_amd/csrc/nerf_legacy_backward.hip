@@ -207,34 +207,31 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
             const f32x4 dh[1] = {*(const f32x4*)dhead};
             layer_wide_v4<1>(pipe, acc, dh);
         }
-        // ---- L9, L8: LayerNorm / ReLU backward, then dX = W^T dY (hidden columns) ----
+        // ---- L9, L8, [density head joins: dX'_7 += Wd^T d(density)], L7 .. L1 (L4: hidden columns only, the
+        // encodings take no gradient), L0's LayerNorm backward: ONE code instance of the layer body, two runs of
+        // the same loop (three copies of the LayerNorm backward and two of the 16-stage loop cost this kernel
+        // 356 B of scratch per lane, 85 accesses inside the loops) ----
+        int l = 9;
 #pragma unroll 1
-        for (int l = 9; l >= 8; --l) {
-            relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
-                                gb + l * 2 * kHidden, turn);
-#pragma unroll
-            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-            layer_wide<16>(pipe, acc, act,
-                           LegacyHook{turn, xbase + ba.L.xhat[l - 1], stat + ba.L.rstd[l - 1],
-                                      stat + ba.L.shift[l - 1], xh, rstd, shift});
-        }
-        // ---- density head joins: dX'_7 += Wd^T d(density) ----
-        {
-            const f32x4 dh[1] = {*(const f32x4*)dhead};
-            layer_wide_v4<1>(pipe, acc, dh);
-        }
-        // ---- L7 .. L1 (L4: hidden columns only, the encodings take no gradient) ----
+        for (int phase = 0; phase < 2; ++phase) {
+            const int last = phase == 0 ? 8 : 0;
 #pragma unroll 1
-        for (int l = 7; l >= 1; --l) {
-            relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
-                                gb + l * 2 * kHidden, turn);
+            for (; l >= last; --l) {
+                relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
+                                    gb + l * 2 * kHidden, turn);
+                if (l == 0) break;
+                const int ln = l - 1;
 #pragma unroll
-            for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-            layer_wide<16>(pipe, acc, act,
-                           LegacyHook{turn, xbase + ba.L.xhat[l - 1], stat + ba.L.rstd[l - 1],
-                                      stat + ba.L.shift[l - 1], xh, rstd, shift});
+                for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                layer_wide<16>(pipe, acc, act,
+                               LegacyHook{turn, xbase + ba.L.xhat[ln], stat + ba.L.rstd[ln], stat + ba.L.shift[ln], xh,
+                                          rstd, shift});
+            }
+            if (phase == 0) {
+                const f32x4 dh[1] = {*(const f32x4*)dhead};
+                layer_wide_v4<1>(pipe, acc, dh);
+            }
         }
-        relu_layer_norm_bwd(gamma, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[0], gb, turn);
         // layer 0's partials: no 4-stage loop follows inside this item (the next item opens with the
         // one-stage color head), so the four waves take their turns here, a barrier apart
         for (int t = 0; t < kWavesPerWg; ++t) {

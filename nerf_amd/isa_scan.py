@@ -168,3 +168,32 @@ def scan(path):
     return found
 
 
+def scratch_report(path):
+    """-> {kernel: (scratch bytes per lane, scratch accesses between two MFMAs)} of one kept assembly file.
+    Bytes = the kernel descriptor's `.amdhsa_private_segment_fixed_size`; "between two MFMAs" = scratch_load /
+    scratch_store instructions with an MFMA within 40 instructions on BOTH sides, i.e. inside an MFMA loop proper
+    (the VALU phases between two loops — LayerNorm, encoding, compositing — are hundreds of instructions long).
+    A spill inside a loop is a vector-memory operation in the in-order vmcnt queue of the stage hand-overs; one in a
+    VALU phase costs its issue slot.  tests/test_build_hygiene.py holds every kernel to a budget."""
+    import bisect
+    text = open(path).read()
+    sizes = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\s+(?:.*\n)*?\s*\.amdhsa_private_segment_fixed_size (\d+)", text):
+        sizes[m.group(1)] = int(m.group(2))
+    out = {}
+    for name, size in sizes.items():
+        start = text.find("\n" + name + ":")
+        if start < 0:
+            out[name] = (size, 0)
+            continue
+        ops = [x.strip() for x in text[start:text.index(".Lfunc_end", start)].splitlines()]
+        mf = [i for i, x in enumerate(ops) if x.startswith("v_mfma")]
+        near = 0
+        for i, x in enumerate(ops):
+            if x.startswith("scratch_") and mf:
+                k = bisect.bisect_left(mf, i)
+                if 0 < k < len(mf) and i - mf[k - 1] <= 40 and mf[k] - i <= 40:
+                    near += 1
+        out[name] = (size, near)
+    return out
+

@@ -40,6 +40,16 @@ def resources(source, csrc=None, defines=()):
             mf = [i for i, x in enumerate(ops) if x.startswith("v_mfma")]
             info["mfma"] = len(mf)
             info["scratch_in_loops"] = sum(1 for i, x in enumerate(ops) if x.startswith("scratch_") and mf and mf[0] < i < mf[-1])
+            # inside an MFMA loop proper: an MFMA within 40 instructions on BOTH sides (phases between two loops,
+            # LayerNorm / encoding / compositing, are hundreds of instructions long)
+            import bisect
+            near = 0
+            for i, x in enumerate(ops):
+                if x.startswith("scratch_") and mf:
+                    k = bisect.bisect_left(mf, i)
+                    if 0 < k < len(mf) and i - mf[k - 1] <= 40 and mf[k] - i <= 40:
+                        near += 1
+            info["scratch_between_mfmas"] = near
         rows.append(info)
     return rows
 
@@ -58,4 +68,4 @@ if __name__ == "__main__":
             continue
         short = re.sub(r"^_ZN?\d*_GLOBAL__N_1", "", row["name"])[:70]
         print(f"{short:70s} vgpr {row.get('vgpr')} agpr {row.get('agpr')} sgpr {row.get('sgpr')} scratch {row.get('scratch')} "
-              f"(in loops: {row.get('scratch_in_loops')}) waves/SIMD {row.get('occupancy')} mfma {row.get('mfma')}")
+              f"(first..last MFMA: {row.get('scratch_in_loops')}, between MFMAs: {row.get('scratch_between_mfmas')}) waves/SIMD {row.get('occupancy')} mfma {row.get('mfma')}")
