@@ -30,13 +30,16 @@ extern "C" {
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
-#define NERF_HIP_EUNSUPPORTED (-2) /* network shape other than the compiled-in one     */
+#define NERF_HIP_EUNSUPPORTED (-2) /* network shape outside what the kernels cover         */
 #define NERF_HIP_EHIP (-3)     /* a HIP runtime call failed; see nerf_hip_last_error() */
 
-/* Network shape: hidden_size 256 and encoding_size 32 -> 96 inputs are compiled into the kernels (the
- * constructor defaults of nerf/model.py:471-475); the number of outputs of the last Linear,
- * 1 density + 3 color + segmentation_outputs (nerf/model.py:541-542, :591-592), is a run-time argument
- * `num_outputs` in [4, 64] — the class count is a property of the dataset.  54 for the defaults. */
+/* Network shape (the constructor arguments of nerf/model.py:471-475 that size `prediction_heads`, :525-542):
+ * hidden_size H in [1, 256], encoding_size in {2, 4, .. 32} (inputs of the first Linear = 3 * encoding_size in
+ * {6, 12, .. 96}: nerf/model.py:526, :550-551) and the rows of the last Linear, 1 density + 3 color +
+ * segmentation_outputs (nerf/model.py:541-542, :591-592) in [4, 64], are RUN-TIME arguments of pack / forward /
+ * backward.  The kernels compute at the compiled-in maxima below; a narrower network runs zero-padded inside
+ * them, which is exact (LayerNorm divides by H; nerf_amd/csrc/nerf_layout.h has the argument) and costs what the
+ * full-width network costs.  color_outputs other than 3 is not supported.  256 / 96 / 54 for the defaults. */
 #define NERF_HIP_HIDDEN 256
 #define NERF_HIP_ENC_INPUTS 96
 #define NERF_HIP_DEFAULT_OUTPUTS 54
@@ -64,12 +67,13 @@ size_t nerf_hip_packed_bytes(void);
 /*
  * Re-lay the 22 parameter tensors of NeRF.prediction_heads (nerf/model.py:525-542) into the
  * MFMA-fragment / LDS-image order the kernels stream.  `params` is a HOST array of 22 DEVICE
- * pointers in state_dict order:
- *   prediction_heads.{0.weight[256,96], 0.bias, 1.weight, 1.bias, 3.weight[256,256], 3.bias,
- *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[num_outputs,256], 15.bias[num_outputs]}
+ * pointers in state_dict order (H = hidden, E = enc_inputs):
+ *   prediction_heads.{0.weight[H,E], 0.bias[H], 1.weight[H], 1.bias[H], 3.weight[H,H], 3.bias,
+ *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[num_outputs,H], 15.bias[num_outputs]}
  * Must be called again whenever the parameters change (once per optimiser step).
  */
-int nerf_hip_pack_weights(const float* const* params, int32_t num_outputs, float* packed, void* stream);
+int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t enc_inputs, int32_t num_outputs,
+                          float* packed, void* stream);
 
 /* Where rays come from and what is written; replaces the bodies of
  * NeRF.render_rays (nerf/model.py:596-668) and NeRF.render_image (:670-770). */
@@ -129,6 +133,9 @@ typedef struct NerfHipRenderArgs {
      * reference's defaults; must be what nerf_hip_pack_weights was given).  With 4 (no classes) `seg`
      * must be NULL.  The legacy-network entry points ignore it. */
     int32_t num_outputs;
+    /* hidden_size and 3 * encoding_size of the network (what nerf_hip_pack_weights was given); 0 means the
+     * defaults 256 / 96.  The legacy-network entry points ignore them. */
+    int32_t hidden, enc_inputs;
 } NerfHipRenderArgs;
 
 /* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional
@@ -139,8 +146,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream);
 size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples);
 
 /* Number of fp32 elements of the flat gradient vector: the 22 parameter tensors in state_dict order,
- * each in its PyTorch layout (304,438 for num_outputs = 54; 0 if num_outputs is out of range). */
-size_t nerf_hip_grad_elements(int32_t num_outputs);
+ * each in its PyTorch layout (304,438 for 256 / 96 / 54; 0 if the shape is out of range). */
+size_t nerf_hip_grad_elements(int32_t hidden, int32_t enc_inputs, int32_t num_outputs);
 
 /* Backward of nerf_hip_render_forward w.r.t. the parameters (replaces PyTorch autograd through
  * NeRF.render_rays, driven by loss.backward() at train_conditional_nerf.py:133).  `fwd` must be
@@ -150,7 +157,7 @@ typedef struct NerfHipBackwardArgs {
     NerfHipRenderArgs fwd;
     const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
     const float* d_seg;         /* [n_rays,num_outputs-4] dL/d seg or NULL (RGB-only loss) */
-    float* grad;                /* [nerf_hip_grad_elements(num_outputs)] written (not accumulated) */
+    float* grad;                /* [nerf_hip_grad_elements(hidden, enc_inputs, num_outputs)] written (not accumulated) */
     float* scratch;             /* nerf_hip_backward_scratch_bytes() bytes                 */
 } NerfHipBackwardArgs;
 

@@ -36,6 +36,7 @@ class RenderArgs(ctypes.Structure):
         ("train_workspace", _f32p),
         ("precision", ctypes.c_int32),
         ("num_outputs", ctypes.c_int32),
+        ("hidden", ctypes.c_int32), ("enc_inputs", ctypes.c_int32),
     ]
 
 
@@ -131,14 +132,14 @@ def lib():
     handle.nerf_hip_last_error.restype = ctypes.c_char_p
     handle.nerf_hip_packed_bytes.restype = ctypes.c_size_t
     handle.nerf_hip_pack_weights.restype = ctypes.c_int
-    handle.nerf_hip_pack_weights.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_void_p,
-                                             ctypes.c_void_p]
+    handle.nerf_hip_pack_weights.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     handle.nerf_hip_render_forward.restype = ctypes.c_int
     handle.nerf_hip_render_forward.argtypes = [ctypes.POINTER(RenderArgs), ctypes.c_void_p]
     handle.nerf_hip_train_workspace_bytes.restype = ctypes.c_size_t
     handle.nerf_hip_train_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
     handle.nerf_hip_grad_elements.restype = ctypes.c_size_t
-    handle.nerf_hip_grad_elements.argtypes = [ctypes.c_int32]
+    handle.nerf_hip_grad_elements.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     handle.nerf_hip_backward_scratch_bytes.restype = ctypes.c_size_t
     handle.nerf_hip_backward_scratch_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
     handle.nerf_hip_render_backward.restype = ctypes.c_int

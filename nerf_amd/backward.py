@@ -65,7 +65,8 @@ class RenderRaysFunction(torch.autograd.Function):
                          packed=ctx.packed, rgb=rgb, seg=seg if model.segmentation_outputs > 0 else None,
                          train_workspace=ctx.workspace,
                          precision=ctx.precision)
-        grad = torch.empty(lib.nerf_hip_grad_elements(model.num_outputs), dtype=torch.float32, device=device)
+        grad = torch.empty(lib.nerf_hip_grad_elements(model.hidden_size, model.enc_inputs, model.num_outputs),
+                           dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
         args.d_rgb, args.d_seg = _lib.ptr(d_rgb), _lib.ptr(d_seg)
         args.grad, args.scratch = _lib.ptr(grad), _lib.ptr(scratch)

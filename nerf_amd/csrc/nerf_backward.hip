@@ -51,6 +51,7 @@ struct BwdArgs {
     float* grad;
     int32_t splits, data_grid;
     int64_t tiles_per_split, n_tiles;
+    float inv_n;                // 1 / hidden_size (the LayerNorm backward's means: nerf_layout.h, Shape)
 };
 
 typedef WeightPipe<kBwdStages> BwdPipe;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
                 layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
-                                    ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn);
+                                    ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn, ba.inv_n);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 layer_wide<kStagesHidden>(pipe, acc, act,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
                                                   ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
             layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
-                                gb, turn);
+                                gb, turn, ba.inv_n);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
             for (int L = 4; L >= 0; --L) {
                 layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                           ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
-                                          turn, unscale);
+                                          turn, ba.inv_n, unscale);
                 if (L == 0) break;                // dy[0] feeds only the weight gradient
                 // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
                 // all of them younger than the two stages this layer's loop opens first
@@ -301,24 +302,15 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) 
 // ---------------------------------------------------------------------------------------------
 // deterministic reduction of the partials into the flat gradient vector
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int layer0_kernel_column(int feature) {
-    // inverse of nerf_layout::layer0_source_feature
-    const int part = feature / 48, rem = feature % 48;
-    const int scale = rem / 3, coord = rem % 3;
-    const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
-    return 16 * (q / 4) + 4 * g + (q % 4);
-}
-
 constexpr int kReduceThreads = 256;
 constexpr int kGbElements = 5 * 2 * kHidden;                       // gamma / beta gradients
 constexpr int kReduceGbBlocks = kGbElements / 4;                   // one wave per element
 
-__device__ __forceinline__ void locate(int e, int n_out, int& tensor, int& idx) {
+__device__ __forceinline__ void locate(int e, const Shape& sh, int& tensor, int& idx) {
     tensor = 0;
     int off = 0;
     for (;;) {
-        const int L = tensor / 4, which = tensor % 4;
-        const int n = tensor_elements(tensor, n_out);
+        const int n = tensor_elements(tensor, sh);
         if (e < off + n) break;
         off += n;
         ++tensor;
@@ -331,27 +323,28 @@ __device__ __forceinline__ void locate(int e, int n_out, int& tensor, int& idx) 
 // per data-gradient WORKGROUP (up to 1,024 terms): one wave per element, lane l sums partials
 // l, l + 64, ... and the lanes combine in a fixed butterfly — still one fixed association.
 __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
-    const int direct_blocks = (grad_elements(ba.a.num_outputs) + kReduceThreads - 1) / kReduceThreads;
+    const Shape sh = shape_of(ba.a);
+    const int direct_blocks = (grad_elements(sh) + kReduceThreads - 1) / kReduceThreads;
     if ((int)blockIdx.x >= direct_blocks) {
         const int lane = threadIdx.x & 63;
         const int ge = ((int)blockIdx.x - direct_blocks) * 4 + (threadIdx.x >> 6);   // [layer][gamma|beta][256]
         const int L = ge / (2 * kHidden), which = (ge / kHidden) & 1, idx = ge % kHidden;
         const float* p = ba.gb_partial + ge;
         const float sum = wave_strided_sum(p, ba.data_grid, kGbFloats, lane);
-        if (lane == 0) ba.grad[grad_offset(4 * L + 2 + which, ba.a.num_outputs) + idx] = sum;
+        if (lane == 0 && idx < sh.hidden) ba.grad[grad_offset(4 * L + 2 + which, sh) + idx] = sum;
         return;
     }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= grad_elements(ba.a.num_outputs)) return;
+    if (e >= grad_elements(sh)) return;
     int tensor, idx;
-    locate(e, ba.a.num_outputs, tensor, idx);
+    locate(e, sh, tensor, idx);
     const int L = tensor / 4, which = tensor % 4;
     if (which >= 2) return;                       // gamma / beta: the blocks behind
     int so;
-    if (which == 0) {
-        if (L == 0) so = kSlabW0 + (idx / kEncIn) * kEncIn + layer0_kernel_column(idx % kEncIn);
-        else if (L == 5) so = kSlabW5 + idx;
-        else so = kSlabWh + (L - 1) * kHidden * kHidden + idx;
+    if (which == 0) {          // (row, column) of the tensor -> its place in the full-width slab
+        if (L == 0) so = kSlabW0 + (idx / sh.enc_in) * kEncIn + layer0_kernel_column(idx % sh.enc_in, sh.scales());
+        else if (L == 5) so = kSlabW5 + (idx / sh.hidden) * kHidden + idx % sh.hidden;
+        else so = kSlabWh + (L - 1) * kHidden * kHidden + (idx / sh.hidden) * kHidden + idx % sh.hidden;
     } else {
         so = kSlabB + L * kHidden + idx;
     }
@@ -384,10 +377,11 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     const NerfHipRenderArgs& a = args->fwd;
     if (args->grad == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad is null");
-    if (a.num_outputs < kMinOutputs || a.num_outputs > kOutPad)
-        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_backward: num_outputs must be 4 .. 64");
+    if (!shape_ok(shape_of(a)))
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_backward: network shape out of range (hidden 1 .. 256, enc_inputs "
+                                                        "6 .. 96 in steps of 6, num_outputs 4 .. 64)");
     if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
-        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)grad_elements(a.num_outputs) * sizeof(float),
+        return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)grad_elements(shape_of(a)) * sizeof(float),
                                                      (hipStream_t)stream), "render_backward memset");
     if (args->scratch == nullptr || args->d_rgb == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: scratch / d_rgb is null");
@@ -413,6 +407,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.splits = choose_splits(ba.n_tiles);
     ba.tiles_per_split = (ba.n_tiles + ba.splits - 1) / ba.splits;
     ba.slabs = args->scratch;
+    ba.inv_n = 1.0f / (float)shape_of(a).hidden;
     ba.gb_partial = args->scratch + (size_t)kMaxSplits * kSlabFloats;
     ba.dymax = ba.gb_partial + (size_t)kMaxDataGrid * kGbFloats;
 
@@ -452,7 +447,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
     else
         hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
-    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(a.num_outputs) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
+    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(shape_of(a)) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
                        0, st, ba);
     return nerf_common::check_hip(hipGetLastError(), "render_backward launch");
 }

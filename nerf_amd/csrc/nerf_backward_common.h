@@ -66,7 +66,9 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
                                                     f32x4 (&acc)[16], float (&act)[64],
                                                     const f32x4 (&xh)[16], float rstd,
                                                     float* dy_row, float* gb_l, GammaBetaTurn& turn,
-                                                    float unscale = 1.0f) {
+                                                    float inv_n, float unscale = 1.0f) {
+    // inv_n = 1 / hidden_size: a narrower network's padded features (nerf_layout.h: Shape) have gamma = beta = 0,
+    // so their gate is closed, their gamma dz is 0 and the two means below run over the real features only
     const f32x4* gam = (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride);
     const f32x4* bet = (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride);
     float s1 = 0.f, s2 = 0.f;
@@ -124,8 +126,8 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     turn.dst = gb_l + 16 * j + 4 * g;             // features 16 j + 4 g + r, added in wave order later
     turn.kg = keep_g;
     turn.kb = keep_b;
-    const float m1 = group_sum(s1) * (1.0f / 256.0f);
-    const float m2 = group_sum(s2) * (1.0f / 256.0f);
+    const float m1 = group_sum(s1) * inv_n;
+    const float m2 = group_sum(s2) * inv_n;
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
         f32x4 dy;

@@ -130,9 +130,10 @@ template <bool kTrain, class Mom, int kOrder = kOrderNormRelu>
 __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 (&raw)[16], const f32x4* gam,
                                                       const f32x4* bet, int g, float* save_row,
                                                       float* save_rstd, float eps = 1e-5f,
-                                                      float save_scale = 1.0f, float* save_shift = nullptr) {
-    const float mean = group_sum(m.sum()) * (1.0f / 256.0f);
-    const float ex2 = group_sum(m.sum_sq()) * (1.0f / 256.0f);
+                                                      float save_scale = 1.0f, float* save_shift = nullptr,
+                                                      const NormDivisor nd = kFullWidth) {
+    const float mean = group_sum(m.sum()) * nd.inv_n;
+    const float ex2 = group_sum(m.sum_sq()) * nd.inv_n;
     float var = ex2 - mean * mean;
     if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
         float v = 0.f;
@@ -144,7 +145,8 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
                 v = __builtin_fmaf(d, d, v);
             }
         }
-        var = group_sum(v) * (1.0f / 256.0f);
+        // (a narrower network's padded features are exactly 0 here: their (0 - mean)^2 terms do not belong)
+        var = (group_sum(v) - nd.padded * mean * mean) * nd.inv_n;
     }
     const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
@@ -164,11 +166,11 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
 template <bool kTrain, class Mom>
 __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
-                                                   float* save_rstd, float eps = 1e-5f,
+                                                   float* save_rstd, const NormDivisor nd, float eps = 1e-5f,
                                                    float save_scale = 1.0f) {
     return finish_moments_at<kTrain, Mom>(m, raw, (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride),
                                           (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride), g,
-                                          save_row, save_rstd, eps, save_scale);
+                                          save_row, save_rstd, eps, save_scale, nullptr, nd);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -75,20 +75,42 @@ constexpr int kHSmallOffset = kHBlobOffset + kBlobFloats;
 constexpr int kBwdHBlobOffset = kHSmallOffset + kSmallFloats;
 constexpr int kPackedFloats = kBwdHBlobOffset + kBwdBlobFloats;
 
-// flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts; n_out = rows of the last Linear
-// (304,438 elements for the reference's default 1 + 3 + 50 outputs)
-__host__ __device__ inline int tensor_elements(int tensor, int n_out) {
+// Network shape at run time (include/nerf_hip.h: hidden / enc_inputs / num_outputs of the argument blocks): the kernels always compute the compiled-in
+// 256 / 96 / 64 widths; a narrower network (hidden_size H <= 256, encoding_size with S = enc / 2 <= 16 scales,
+// i.e. 6 S <= 96 inputs) runs ZERO-PADDED inside them, which is exact:
+//   * padded rows / columns of every weight matrix, padded biases, gamma and beta are zero in the packed images,
+//     so a padded feature carries 0 into every product and the padded scales of the encoding meet zero weights;
+//   * LayerNorm divides its sums by H, not 256 (the padded pre-activations are exactly 0 and add nothing to the
+//     sum or the sum of squares; the two-pass fallback subtracts their (0 - mean)^2 terms);
+//   * a padded feature's normalised value is not zero, but gamma = beta = 0 makes its activation, its ReLU gate
+//     and every gradient that reaches a REAL parameter through it exactly zero; what the backward computes for
+//     padded parameters is never copied into the flat gradient.
+// The cost is that of the full-width network.
+struct Shape {
+    int hidden;                 // H
+    int enc_in;                 // 6 S: inputs of layer 0, [sin: scale-major x coord-minor | shifted: same] (model.py:158-163)
+    int n_out;                  // rows of the last Linear
+    __host__ __device__ int scales() const { return enc_in / 6; }
+};
+__host__ __device__ inline bool shape_ok(const Shape& s) {
+    return s.hidden >= 1 && s.hidden <= kHidden && s.enc_in >= 6 && s.enc_in <= kEncIn && s.enc_in % 6 == 0 &&
+           s.n_out >= kMinOutputs && s.n_out <= kOutPad;
+}
+
+// flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts
+// (304,438 elements for the reference's defaults: hidden 256, 96 inputs, 1 + 3 + 50 outputs)
+__host__ __device__ inline int tensor_elements(int tensor, const Shape& s) {
     // tensor index in state_dict order: 4 L + {0 W, 1 b, 2 gamma, 3 beta} for L < 5; 20 W5, 21 b5
     const int L = tensor / 4, which = tensor % 4;
-    if (which == 0) return L == 0 ? kHidden * kEncIn : (L == 5 ? n_out * kHidden : kHidden * kHidden);
-    return L == 5 ? n_out : kHidden;
+    if (which == 0) return L == 0 ? s.hidden * s.enc_in : (L == 5 ? s.n_out * s.hidden : s.hidden * s.hidden);
+    return L == 5 ? s.n_out : s.hidden;
 }
-__host__ __device__ inline int grad_offset(int tensor, int n_out) {
+__host__ __device__ inline int grad_offset(int tensor, const Shape& s) {
     int off = 0;
-    for (int i = 0; i < tensor; ++i) off += tensor_elements(i, n_out);
+    for (int i = 0; i < tensor; ++i) off += tensor_elements(i, s);
     return off;
 }
-__host__ __device__ inline int grad_elements(int n_out) { return grad_offset(22, n_out); }
+__host__ __device__ inline int grad_elements(const Shape& s) { return grad_offset(22, s); }
 
 // Input-feature permutation of layer 0: lane group g computes, for the Gaussian of its sample,
 // the 12 (scale, coord) pairs with scale index 4 g .. 4 g + 3; local slot q = 4 t + r:
@@ -99,6 +121,21 @@ __host__ __device__ inline int layer0_source_feature(int t, int g, int r) {
     const int part = q / 12, p = q % 12;
     const int scale = 4 * g + p / 3, coord = p % 3;
     return part * 48 + 3 * scale + coord;
+}
+// The same slot for a network with `scales` <= 16 scales (encoding_size = 2 scales): its source feature in the
+// reference's [sin: scales x 3 | shifted: scales x 3] order, or -1 for a scale the network does not have.
+__host__ __device__ inline int layer0_source_feature(int t, int g, int r, int scales) {
+    const int q = 4 * t + r;
+    const int part = q / 12, p = q % 12;
+    const int scale = 4 * g + p / 3, coord = p % 3;
+    return scale < scales ? part * 3 * scales + 3 * scale + coord : -1;
+}
+// ... and back: kernel column (16 t + 4 g + r) of source feature f
+__host__ __device__ inline int layer0_kernel_column(int f, int scales) {
+    const int part = f / (3 * scales), rem = f % (3 * scales);
+    const int scale = rem / 3, coord = rem % 3;
+    const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
+    return 16 * (q / 4) + 4 * g + (q % 4);
 }
 
 }  // namespace nerf_layout

@@ -32,6 +32,7 @@ struct KernelArgs {
     int32_t chunks;             // ceil(P / 16)
     int64_t groups;             // ceil(n_rays / 4)
     TrainLayout save;           // offsets into a.train_workspace (training forward only)
+    NormDivisor norm;           // 1 / hidden_size and the padded feature count of the LayerNorms (nerf_layout.h: Shape)
 };
 
 typedef WeightPipe<kNumStages> FwdPipe;
@@ -332,19 +333,19 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 load_bias16(small, g, Y);
                 layer_fused_h<3, false, kTrain>(pipe, X, Y, norm, mom);
                 norm = finish_moments<kTrain, HMoments>(mom, Y, small, g, xrow + ka.save.xhat[0],
-                                                        rstd_p + ka.save.rstd[0], eps, rs);
+                                                        rstd_p + ka.save.rstd[0], ka.norm, eps, rs);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
                     const float* small_a = small + L * kSmallPerLayerLds;
                     load_bias16(small_a, g, X);
                     layer_fused_h<8, true, kTrain>(pipe, Y, X, norm, mom);
                     norm = finish_moments<kTrain, HMoments>(mom, X, small_a, g, xrow + ka.save.xhat[L],
-                                                            rstd_p + ka.save.rstd[L], eps, rs);
+                                                            rstd_p + ka.save.rstd[L], ka.norm, eps, rs);
                     const float* small_b = small_a + kSmallPerLayerLds;
                     load_bias16(small_b, g, Y);
                     layer_fused_h<8, true, kTrain>(pipe, X, Y, norm, mom);
                     norm = finish_moments<kTrain, HMoments>(mom, Y, small_b, g, xrow + ka.save.xhat[L + 1],
-                                                            rstd_p + ka.save.rstd[L + 1], eps, rs);
+                                                            rstd_p + ka.save.rstd[L + 1], ka.norm, eps, rs);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             // ---- layer 0: 96 -> 256 ----
             load_bias16(small, g, Y);
             layer_fused<kStagesL0, false, kTrain>(pipe, X, Y, norm, mom);
-            norm = finish_moments<kTrain, Moments>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0]);
+            norm = finish_moments<kTrain, Moments>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0], ka.norm);
             // ---- layers 1..4: 256 -> 256 ----
 #pragma unroll 1
             for (int L = 1; L <= 4; ++L) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 load_bias16(small_l, g, Y);
                 layer_fused<kStagesHidden, true, kTrain>(pipe, X, Y, norm, mom);
                 norm = finish_moments<kTrain, Moments>(mom, X, small_l, g, xrow + ka.save.xhat[L],
-                                              rstd_p + ka.save.rstd[L]);
+                                              rstd_p + ka.save.rstd[L], ka.norm);
             }
             // ---- layer 5: 256 -> 54 (padded 64) ----
             {
@@ -450,6 +451,20 @@ struct PackArgs {
     const float* p[NERF_HIP_NUM_PARAM_TENSORS];
     float* packed;
     int32_t n_out;              // rows of the last Linear (1 + 3 + segmentation classes); padded to 64 with zeros
+    int32_t hidden, enc_in;     // H and 6 x scales of the source tensors; the images are zero beyond them (nerf_layout.h)
+    // element (out, in) of the source matrices, 0 in the padding: layer 0 by kernel slot (t, g, r), the hidden
+    // layers L = 1..4, the last layer; element f of a per-feature vector (bias / gamma / beta: tensor index)
+    __device__ __forceinline__ float w0(int out, int t, int g, int r) const {
+        const int src = layer0_source_feature(t, g, r, enc_in / 6);
+        return out < hidden && src >= 0 ? p[0][out * enc_in + src] : 0.f;
+    }
+    __device__ __forceinline__ float wh(int L, int out, int in) const {
+        return out < hidden && in < hidden ? p[4 * L][out * hidden + in] : 0.f;
+    }
+    __device__ __forceinline__ float w5(int out, int in) const {
+        return out < n_out && in < hidden ? p[20][out * hidden + in] : 0.f;
+    }
+    __device__ __forceinline__ float vec(int tensor, int f) const { return f < hidden ? p[tensor][f] : 0.f; }
 };
 
 __global__ void nerf_pack_kernel(const PackArgs pa) {
@@ -464,17 +479,17 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         const int row = lane & 15, g = lane >> 4;
         if (stage < kStagesL0) {                                    // layer 0: W[256,96]
             const int out = 16 * quad + row;
-            v = pa.p[0][out * kEncIn + layer0_source_feature(stage, g, r)];
+            v = pa.w0(out, stage, g, r);
         } else if (stage < kStagesL0 + 4 * kStagesHidden) {         // layers 1..4: W[256,256]
             const int L = 1 + (stage - kStagesL0) / kStagesHidden;
             const int t = (stage - kStagesL0) % kStagesHidden;
             const int out = 16 * quad + row;
-            v = pa.p[4 * L][out * kHidden + 16 * t + 4 * g + r];
+            v = pa.wh(L, out, 16 * t + 4 * g + r);
         } else {                                                    // layer 5: W[54,256]
             const int s = stage - (kStagesL0 + 4 * kStagesHidden);
             const int t = 4 * s + quad / 4, T = quad % 4;
             const int out = 16 * T + row;
-            if (out < pa.n_out) v = pa.p[20][out * kHidden + 16 * t + 4 * g + r];
+            v = pa.w5(out, 16 * t + 4 * g + r);
         }
     } else if (e >= kBwdHBlobOffset) {
         // transposed split-precision image (nerf_layout.h): two f16 of one slab per float slot
@@ -494,13 +509,13 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             if (stage < kStagesL5) {
                 const int half = stage / 2, m = stage % 2;
                 const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
-                if (out < pa.n_out) w = pa.p[20][out * kHidden + 16 * (8 * half + pair) + row];
+                w = pa.w5(out, 16 * (8 * half + pair) + row);
             } else {
                 const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
                 const int s = (stage - kStagesL5) % kStagesHidden;
                 const int half = s / 8, m = s % 8;
                 const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
-                w = pa.p[4 * L][out * kHidden + 16 * (8 * half + pair) + row];
+                w = pa.wh(L, out, 16 * (8 * half + pair) + row);
             }
             w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
             const _Float16 hi = (_Float16)w;              // round to nearest
@@ -518,7 +533,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int g = q / 64, T = (q % 64) / 4, reg = q & 3;
             const int f = 16 * T + 4 * g + reg;
             const int tensor = which == 0 ? 4 * L + 1 : (which == 1 ? 4 * L + 2 : 4 * L + 3);
-            v = pa.p[tensor][f] * (which == 0 ? sb : sx);
+            v = pa.vec(tensor, f) * (which == 0 ? sb : sx);
         } else {
             const int q = i - 5 * kSmallPerLayer;
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
@@ -544,18 +559,18 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             if (stage < kStagesL0) {
                 const int half = stage / 3, m = stage % 3;
                 const int out = 16 * (8 * half + pair) + row;
-                w = pa.p[0][out * kEncIn + layer0_source_feature(2 * m + tl, kg, r)];
+                w = pa.w0(out, 2 * m + tl, kg, r);
             } else if (stage < kStagesL0 + 4 * kStagesHidden) {
                 const int L = 1 + (stage - kStagesL0) / kStagesHidden;
                 const int s = (stage - kStagesL0) % kStagesHidden;
                 const int half = s / 8, m = s % 8;
                 const int out = 16 * (8 * half + pair) + row;
-                w = pa.p[4 * L][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
+                w = pa.wh(L, out, 32 * m + 16 * tl + 4 * kg + r);
             } else {
                 const int s = stage - (kStagesL0 + 4 * kStagesHidden);
                 const int m = 2 * s + (pair >> 2), T = pair & 3;
                 const int out = 16 * T + row;
-                if (out < pa.n_out) w = pa.p[20][out * kHidden + 32 * m + 16 * tl + 4 * kg + r];
+                w = pa.w5(out, 32 * m + 16 * tl + 4 * kg + r);
             }
             w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
             const _Float16 hi = (_Float16)w;              // round to nearest
@@ -573,11 +588,11 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         const int i = lane & 15, g = lane >> 4;
         if (stage < kStagesL5) {
             const int out = 16 * stage + 4 * g + r;
-            if (out < pa.n_out) v = pa.p[20][out * kHidden + 16 * tin + i];
+            v = pa.w5(out, 16 * tin + i);
         } else {
             const int L = 4 - (stage - kStagesL5) / kStagesHidden;      // 4, 3, 2, 1
             const int tout = (stage - kStagesL5) % kStagesHidden;
-            v = pa.p[4 * L][(16 * tout + 4 * g + r) * kHidden + 16 * tin + i];
+            v = pa.wh(L, 16 * tout + 4 * g + r, 16 * tin + i);
         }
     } else {
         const int i = e - kBlobFloats;
@@ -587,7 +602,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int g = q / 64, T = (q % 64) / 4, reg = q & 3;
             const int f = 16 * T + 4 * g + reg;
             const int tensor = which == 0 ? 4 * L + 1 : (which == 1 ? 4 * L + 2 : 4 * L + 3);
-            v = pa.p[tensor][f];
+            v = pa.vec(tensor, f);
         } else {
             const int q = i - 5 * kSmallPerLayer;                   // last bias [g][T(4)][reg]
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
@@ -619,18 +634,22 @@ size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
     return (size_t)make_train_layout(n_rays, chunks).total * sizeof(float);
 }
 
-size_t nerf_hip_grad_elements(int32_t num_outputs) {
-    if (num_outputs < kMinOutputs || num_outputs > kOutPad) return 0;
-    return (size_t)grad_elements(num_outputs);
+size_t nerf_hip_grad_elements(int32_t hidden, int32_t enc_inputs, int32_t num_outputs) {
+    const Shape s{hidden, enc_inputs, num_outputs};
+    return shape_ok(s) ? (size_t)grad_elements(s) : 0;
 }
 
-int nerf_hip_pack_weights(const float* const* params, int32_t num_outputs, float* packed, void* stream) {
+int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t enc_inputs, int32_t num_outputs,
+                          float* packed, void* stream) {
     if (params == nullptr || packed == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "pack_weights: null pointer");
-    if (num_outputs < kMinOutputs || num_outputs > kOutPad)
-        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "pack_weights: num_outputs must be 4 .. 64 (1 density + 3 color + segmentation classes)");
+    if (!shape_ok(Shape{hidden, enc_inputs, num_outputs}))
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "pack_weights: hidden must be 1 .. 256, enc_inputs a multiple of 6 in 6 .. 96, "
+                                                        "num_outputs 4 .. 64 (1 density + 3 color + segmentation classes)");
     PackArgs pa;
     pa.n_out = num_outputs;
+    pa.hidden = hidden;
+    pa.enc_in = enc_inputs;
     for (int i = 0; i < NERF_HIP_NUM_PARAM_TENSORS; ++i) {
         if (params[i] == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "pack_weights: null tensor");
         pa.p[i] = params[i];
@@ -649,8 +668,9 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: n_rays / num_samples out of range");
     if (a.packed == nullptr || a.rgb == nullptr || (a.t_table == nullptr && a.t_values == nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: packed / rgb / t_table is null");
-    if (a.num_outputs < kMinOutputs || a.num_outputs > kOutPad)
-        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_forward: num_outputs must be 4 .. 64 (1 density + 3 color + segmentation classes)");
+    if (!shape_ok(shape_of(a)))
+        return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_forward: hidden must be 1 .. 256, enc_inputs a multiple of 6 in 6 .. 96, "
+                                                        "num_outputs 4 .. 64 (1 density + 3 color + segmentation classes)");
     if (a.num_outputs == kMinOutputs && a.seg != nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: seg given but the network has no segmentation classes");
     const bool arrays = a.rays_o != nullptr && a.rays_d != nullptr;
@@ -666,6 +686,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     ka.save = make_train_layout(a.n_rays, ka.chunks);
+    ka.norm = norm_divisor(shape_of(a).hidden);
     const bool train = a.train_workspace != nullptr;
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");

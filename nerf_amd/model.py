@@ -246,14 +246,20 @@ class NeRF(nn.Module):
         """Rows of the last Linear: density | color | segmentation (nerf/model.py:541-542)."""
         return 1 + self.color_outputs + self.segmentation_outputs
 
+    @property
+    def enc_inputs(self):
+        """Inputs of the first Linear: 3 coordinates x encoding_size (nerf/model.py:526)."""
+        return 3 * self.encoding_size
+
     def _check_shape(self):
-        """The kernels take the number of segmentation classes at run time (any count with
-        1 + 3 + classes <= 64 fits the padded 64-row output tile); hidden_size, encoding_size and the three
-        color channels are compiled in (the only shapes the reference's scripts use)."""
-        if (self.hidden_size, self.encoding_size, self.color_outputs) != (256, 32, 3) or \
-                not 0 <= self.segmentation_outputs <= 60:
+        """hidden_size (<= 256), encoding_size (even, <= 32) and the number of segmentation classes (<= 60) are
+        run-time arguments of the kernels: a network narrower than the compiled-in 256 / 96 / 64 runs zero-padded
+        inside them, which is exact (nerf_amd/csrc/nerf_layout.h: Shape) and costs what the full width costs.
+        Three color channels are compiled in (the reference's scripts never use another count)."""
+        if self.color_outputs != 3 or not 1 <= self.hidden_size <= 256 or self.encoding_size % 2 != 0 or \
+                not 2 <= self.encoding_size <= 32 or not 0 <= self.segmentation_outputs <= 60:
             raise NotImplementedError(
-                "libnerf_hip is compiled for hidden_size=256, encoding_size=32, color_outputs=3 and takes "
+                "libnerf_hip takes 1 <= hidden_size <= 256, an even encoding_size in 2 .. 32, color_outputs=3 and "
                 "0 <= segmentation_outputs <= 60 (the reference's defaults: 256 / 32 / 3 / 50)")
 
     def _param_list(self):
@@ -282,8 +288,8 @@ class NeRF(nn.Module):
             packed = torch.empty(lib.nerf_hip_packed_bytes() // 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.nerf_hip_pack_weights(ptrs, self.num_outputs, _lib.ptr(packed), ctypes.c_void_p(stream)),
-                       "nerf_hip_pack_weights")
+            _lib.check(lib.nerf_hip_pack_weights(ptrs, self.hidden_size, self.enc_inputs, self.num_outputs,
+                                                 _lib.ptr(packed), ctypes.c_void_p(stream)), "nerf_hip_pack_weights")
         if not fresh:
             self._packed = packed
         self._packed_key = tuple((p.data_ptr(), p._version) for p in params)
@@ -367,6 +373,7 @@ class NeRF(nn.Module):
         args.out_raw, args.out_weights = _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
         args.num_outputs = self.num_outputs
+        args.hidden, args.enc_inputs = self.hidden_size, self.enc_inputs
         if precision is not None:
             args.precision = precision
             return

@@ -35,9 +35,15 @@ def test_library_exports_every_declared_symbol(handle):
     assert handle.nerf_hip_version() == _lib.ABI_VERSION == 6
     # packed image = {74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB} x {fp32, f16 pairs}
     assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4 + 68 * 16384)
-    assert handle.nerf_hip_grad_elements(54) == 304438        # the reference's 1 + 3 + 50 outputs
-    assert handle.nerf_hip_grad_elements(4) == 304438 - 50 * 257 and handle.nerf_hip_grad_elements(64) == 304438 + 10 * 257
-    assert handle.nerf_hip_grad_elements(3) == 0 and handle.nerf_hip_grad_elements(65) == 0
+    ge = handle.nerf_hip_grad_elements
+    assert ge(256, 96, 54) == 304438                          # the reference's defaults: hidden 256, 3 x 32 inputs, 1 + 3 + 50 outputs
+    assert ge(256, 96, 4) == 304438 - 50 * 257 and ge(256, 96, 64) == 304438 + 10 * 257
+    assert ge(256, 96, 3) == 0 and ge(256, 96, 65) == 0
+    # narrower networks (run zero-padded inside the kernels): sum of the 22 tensors' PyTorch sizes
+    for hid, enc, n_out in ((128, 96, 54), (256, 48, 54), (64, 48, 11), (17, 6, 4)):
+        want = hid * enc + hid + 4 * (hid * hid + hid) + 10 * hid + n_out * hid + n_out
+        assert ge(hid, enc, n_out) == want, (hid, enc, n_out)
+    assert ge(257, 96, 54) == 0 and ge(256, 97, 54) == 0 and ge(256, 102, 54) == 0 and ge(0, 96, 54) == 0
     assert handle.nerf_hip_train_workspace_bytes(4096, 64) == 4096 * 64 * 2793 * 4
     assert handle.nerf_hip_train_workspace_bytes(0, 64) == 0
 
@@ -93,7 +99,7 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     assert b"precision" in handle.nerf_hip_last_error()
     assert handle.nerf_hip_build_flags() == b""          # the product build carries no experiment macro
-    assert handle.nerf_hip_pack_weights(None, 54, None, None) == -1
+    assert handle.nerf_hip_pack_weights(None, 256, 96, 54, None, None) == -1
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()
     assert handle.nerf_hip_render_backward(ctypes.byref(bargs), None) == -1
