@@ -75,7 +75,7 @@ __device__ __forceinline__ void interleave_n() {
     }
 }
 
-constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16, kSpreadDma = 32, kPairUnits = 64, kDmaToRegs = 128, kHalfReads = 256;
+constexpr int kNoDma = 1, kNoBarrier = 2, kNoReads = 4, kNoBuild = 8, kNoMoments = 16, kSpreadDma = 32, kPairUnits = 64, kDmaToRegs = 128, kHalfReads = 256, kBoundary = 512;
 
 // the same four 1 KiB fetches as plain loads into registers nobody reads: the texture path's share of a DMA's cost
 template <class Pipe>
@@ -605,7 +605,17 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void gemm_block_k
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const bbuf = smem + kRing4 * kStageBytes;             // [2][kWaves sample tiles][hi | lo][1 KiB]
+    // kBoundary: per-sample LayerNorm partials of every wave behind the exchange buffer: [wave][sample tile][j] (sum, sum of squares)
+    // (aliased onto the exchange buffer: 80 KiB per 4-wave workgroup is exactly two per CU; this is a timing probe)
+    float* const stats = (float*)bbuf;
     for (int i = threadIdx.x; i < 4096 * kWaves / 4; i += 64 * kWaves) ((float*)bbuf)[i] = a.seed[i & 63] * 0.001f;
+    const float gam = a.seed[lane & 63] * 0.5f + 1.0f, bet = a.seed[(lane + 7) & 63] * 0.1f;
+    f32x4 pending[2][4];                                         // second k block of this wave's outputs, built in the next layer's shadow
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pending[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rstd_q[4] = {1.f, 1.f, 1.f, 1.f}, shift_q[4] = {0.f, 0.f, 0.f, 0.f};
     PipeN<kWaves> pipe;
     pipe.init(a.image, smem, wave, lane);
     pipe.issue();
@@ -670,7 +680,92 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void gemm_block_k
                         acc[t][q] = mfma_h(ah[cur][t], bl[cur][q], acc[t][q]);
                         acc[t][q] = mfma_h(al[cur][t], bh[cur][q], acc[t][q]);
                     }
+                if ((kFlags & kBoundary) && kb == 0) {
+                    // the SECOND k block this wave produces for the layer that has just started (its out tiles 2, 3 of
+                    // the layer before): normalise, ReLU, split, publish — in the shadow of k block 0's 48 MFMAs
+                    h8* dst = (h8*)(bbuf + 2048 * kWaves + side * 8192) + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                v[t][r] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(pending[t][q][r], rstd_q[q], shift_q[q]), gam, bet), 0.f);
+                        h8 hi, lo;
+                        split8(v[0], v[1], hi, lo);
+                        dst[(2 * q) * 64] = hi;
+                        dst[(2 * q + 1) * 64] = lo;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 48; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kFlags & kBoundary) {
+                // ---- what a real layer boundary adds: LayerNorm needs a sample's 256 features, which sit in four waves.
+                // (1) this wave's partial moments of its 64 features for its 64 samples, (2) through LDS + one barrier,
+                // (3) normalise / ReLU / split of the FIRST k block it produces (out tiles 0, 1) and publish it: the next
+                // layer's k block 0 needs it before the first MFMA; the second block waits in registers (`pending`)
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s1[q] += acc[t][q][r];
+                            s2[q] = __builtin_fmaf(acc[t][q][r], acc[t][q][r], s2[q]);
+                        }
+                    s1[q] = group_sum(s1[q]);
+                    s2[q] = group_sum(s2[q]);
+                }
+                const int j = lane & 15, g = lane >> 4;
+                if (g == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(float2*)(stats + ((wave * 4 + q) * 16 + j) * 2) = float2{s1[q], s2[q]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float2 p = *(const float2*)(stats + (((side * 4 + w) * 4 + q) * 16 + j) * 2);
+                        m1 += p.x;
+                        m2 += p.y;
+                    }
+                    const float mean = m1 * (1.0f / 256.0f), var = m2 * (1.0f / 256.0f) - mean * mean;
+                    const float rs = __builtin_amdgcn_rsqf(var + 1e-5f);
+                    rstd_q[q] = rs;
+                    shift_q[q] = -mean * rs;
+                }
+                h8* dst = (h8*)(bbuf + side * 8192) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[t][r] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[t][q][r], rstd_q[q], shift_q[q]), gam, bet), 0.f);
+                    h8 hi, lo;
+                    split8(v[0], v[1], hi, lo);
+                    dst[(2 * q) * 64] = hi;
+                    dst[(2 * q + 1) * 64] = lo;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) pending[t][q] = acc[2 + t][q];
+                }
+                // (the publish barrier is the next k block's hand-over; bias = the accumulators' start value)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{gam, bet, gam, bet};
             }
         }
 #pragma unroll
@@ -810,6 +905,10 @@ int main() {
             run(gemm_block_kernel<kNoDma | kNoBarrier, 4>, 4, "  without stream and hand-over");
             run(gemm_block_kernel<0, 8>, 8, "4 x 4 blocks, ONE 8-wave workgroup per CU");
             run(gemm_block_kernel<kNoDma, 8>, 8, "  the same without the weight stream");
+            // ... and with what a real layer boundary adds (LayerNorm partials through LDS + barrier, normalise /
+            // split / publish of the wave's first k block exposed, of its second in the next layer's shadow)
+            run(gemm_block_kernel<kBoundary, 4>, 4, "4 x 4 blocks, 4 waves, WITH layer boundaries");
+            run(gemm_block_kernel<kBoundary, 8>, 8, "4 x 4 blocks, 8 waves, WITH layer boundaries");
         }
         printf("two-tile loop (one wave per SIMD), same switches:\n");
         run_two<0>(a, lds, e0, e1, "as written");
