@@ -82,7 +82,7 @@ def test_forward_vs_oracle(shape, precision):
         heavy = want.exp() > 1e-3
         floor = float((want.double() - seg64[ok])[heavy].abs().max())
         assert (got - want)[heavy].abs().max() <= 1e-4 + 4 * floor, floor
-        assert (got.exp() - want.exp()).abs().max() <= 1e-6
+        assert (got.exp() - want.exp()).abs().max() <= 1e-5        # (the bar of the RGB composite)
         # the classes: the classes of a ray sum (in probability) to the ray's total weight, at most 1
         assert float(seg[:, 0].exp().sum(-1).max()) <= 1.0 + 1e-4
     with torch.no_grad():
