@@ -31,7 +31,7 @@ def headers():
 # (v_pk_mul_f32 ...) and folds operand swaps into their op_sel modifiers.  On MI355X a packed fp32
 # instruction whose LOW result selects the HIGH register of a source (op_sel bit set) returns that
 # result as if the operand were 0 in lanes 48-63 while the SIMD's other wave executes
-# v_mfma_f32_16x16x32_{f16,bf16} (scripts/probes/pk_vs_mfma_coexec.hip): the
+# v_mfma_f32_16x16x32_{f16,bf16} (scripts/probes/pk_vs_mfma_coexec.hip, NOTES.md section 7b): the
 # kernels must not contain such instructions, and rule R5 of the ISA scan — run on every build, below —
 # fails the build if one appears.  Hand-written f32x2 code never swaps halves, so it is unaffected.
 CODEGEN_FLAGS = ["-O3", "-std=c++17"]

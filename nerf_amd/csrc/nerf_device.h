@@ -12,7 +12,7 @@
 #include "nerf_common.h"
 
 // wave priorities: a wave in a VALU phase (encoding, LayerNorm, compositing) above a wave inside an
-// MFMA loop (the other orders were measured and lose: DESIGN.md section 7)
+// MFMA loop (the other orders were measured and lose: NOTES.md section 7)
 #define NERF_PRIO_MFMA 0
 #define NERF_PRIO_VALU 2
 
