@@ -176,24 +176,43 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     // one (padded ray, chunk) item per wave: dL/d(out) of every sample was written by
     // nerf_composite_bwd_kernel (the suffix sum along the ray lives there), so the chunks of a ray
     // are independent here and a small batch still fills the chip
+    // Addresses: a wave's 16-sample tile is wave-UNIFORM, so every saved row is (uniform 64-bit base of the tile, in
+    // SGPRs) + (this lane's constant 32-bit offset inside a tile) — no per-lane 64-bit pointer stays live across the
+    // loops.  That is not only two or three registers per pointer: a spilled pointer that the compiler reloads BEHIND
+    // a layer's burst of 16 saves + 16 loads gets a `s_waitcnt vmcnt(0)`, and vmcnt retires in order — the reload of
+    // an L1-resident scratch line then waits for the whole burst's HBM round trip (round 4: one such reload, for the
+    // 1/std address, cost this kernel a fifth of its time; scripts/vmcnt_drains.py finds them in the assembly).
+    // (lane_word: the same value behind an optimisation barrier, taken at every use — otherwise loop-invariant code
+    //  motion folds the offset into a per-lane 64-bit pointer again, and that pointer is what gets spilled)
+    auto lane_word = [](uint32_t v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    const uint32_t row_off = (uint32_t)(j * kHidden + 4 * g);          // floats, in a [16][256] tile
+    const uint32_t out_off = (uint32_t)(j * kOutPad + 4 * g);          // floats, in a [16][64] tile
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
-        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c   (uniform)
         {
-            const int64_t sp = tile * 16 + j;
+            const float* const ws_rows = ws + tile * (16 * kHidden);     // + L.xhat[l] / L.dy[l]: this tile's rows
+            const float* const ws_stat = ws + tile * 16;                 // + L.rstd[l]: this tile's 16 scalars
             f32x4 dout[4];
             {
-                const float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+                const float* drow = ws + ba.L.dy5 + tile * (16 * kOutPad);
+                const uint32_t oo = lane_word(out_off);
 #pragma unroll
-                for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
+                for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + oo + T * 16);
             }
 
             f32x4 xh[16];
             float rstd;
             // x_hat / 1/std of layer 4 first: 17 loads that fly under the 4 stages of layer 5
-            const float* xrow = ws + ba.L.xhat[4] + sp * kHidden + 4 * g;
+            {
+                const float* xrow = ws_rows + ba.L.xhat[4];
+                rstd = (ws_stat + ba.L.rstd[4])[lane_word(j)];
+                const uint32_t ro = lane_word(row_off);
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow + T * 16);
-            rstd = ws[ba.L.rstd[4] + sp];
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow + ro + T * 16);
+            }
             float unscale;
             {
                 float m = 0.f;
@@ -212,15 +231,19 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
 #pragma unroll 1
             for (int L = 4; L >= 0; --L) {
                 layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
-                                          ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden,
+                                          const_cast<float*>(ws_rows) + ba.L.dy[L] + lane_word(row_off), gb + L * 2 * kHidden,
                                           turn, ba.inv_n, unscale);
                 if (L == 0) break;                // dy[0] feeds only the weight gradient
-                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above,
-                // all of them younger than the two stages this layer's loop opens first
-                const float* xrow_n = ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g;
+                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above (1/std first: its
+                // address is the one thing here that is not a row offset), all of them younger than the two stages
+                // this layer's loop opens first
+                {
+                    const float* xrow_n = ws_rows + ba.L.xhat[L - 1];
+                    rstd = (ws_stat + ba.L.rstd[L - 1])[lane_word(j)];
+                    const uint32_t ro = lane_word(row_off);
 #pragma unroll
-                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);
-                rstd = ws[ba.L.rstd[L - 1] + sp];
+                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);
+                }
                 // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
                 // workgroup's maximum) the weight-gradient kernel's
                 float m = 0.f;

@@ -43,6 +43,10 @@ VARIANTS = {
     "noloads": [("                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);\n                rstd = ws[ba.L.rstd[L - 1] + sp];",
                  "                for (int T = 0; T < 16; ++T) { xh[T] = f32x4{0.5f, -0.25f, 0.125f, 1.0f}; asm volatile(\"\" : \"+v\"(xh[T])); }\n                rstd = 1.0f; asm volatile(\"\" : \"+v\"(rstd));")],
     "nonote": [("                note_max(wmax + L, amax, lane);", "")],
+    # no weight stream: the LDS-DMA of every stage is skipped (the ring keeps whatever it held; hand-over waits and
+    # barriers stay) — what the data gradient's own loads and saves cost when they do not share the CU's vector-memory
+    # path with 20 GB/s of weights
+    "nodma": [("                \"global_load_lds_dwordx4 %1, %3\\n\\t\"\n                \"global_load_lds_dwordx4 %1, %3 offset:1024\\n\\t\"\n                \"global_load_lds_dwordx4 %1, %3 offset:2048\\n\\t\"\n                \"global_load_lds_dwordx4 %1, %3 offset:3072\\n\\t\"\n", "")],
 }
 
 
@@ -50,14 +54,18 @@ def patch(src, variant=None):
     s = open(src).read()
     if variant:
         common = os.path.join(os.path.dirname(src), "nerf_backward_common.h")
-        c = open(common).read()
+        device = os.path.join(os.path.dirname(src), "nerf_device.h")
+        c, dv = open(common).read(), open(device).read()
         for name in variant.split("+"):
             for old, new in VARIANTS[name]:
                 if old in s:
                     s = s.replace(old, new)
-                else:
-                    assert old in c, (name, old)
+                elif old in c:
                     c = c.replace(old, new)
+                else:
+                    assert old in dv, (name, old)
+                    dv = dv.replace(old, new)
+        open(device, "w").write(dv)
         open(common, "w").write(c)
     s = s.replace("constexpr int kYoungerL5 = 17, kYoungerHidden = 33;",
                   "constexpr int kYoungerL5 = 17, kYoungerHidden = 33;" + STAMP_MACRO)

@@ -15,6 +15,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// kMode 2 / 3: the kernel's order and coupling — the 16 saves (computed data) FIRST, then the 17 independent loads,
+// consumed only after the pause; mode 3 also puts the workgroup's four waves through a barrier in front of every
+// burst, as the weight ring's per-stage barrier does in the kernel (all four burst at the same instant)
 template <int kMode>
 __global__ __launch_bounds__(256, 2) void probe(const float* xhat, float* dy, int64_t items, int64_t mp, int pause,
                                                 float* sink) {
@@ -27,6 +30,16 @@ __global__ __launch_bounds__(256, 2) void probe(const float* xhat, float* dy, in
             const float* src = xhat + (int64_t)L * mp * 256 + item * 16 * 256;
             float* dst = dy + (int64_t)L * mp * 256 + item * 16 * 256;
             f32x4 x[16];
+            if (kMode >= 2) {
+                if (kMode == 3) __syncthreads();
+#pragma unroll
+                for (int T = 0; T < 16; ++T) *(f32x4*)(dst + j * 256 + 4 * g + T * 16) = keep + (float)T;
+#pragma unroll
+                for (int T = 0; T < 16; ++T) x[T] = *(const f32x4*)(src + j * 256 + 4 * g + T * 16);
+                for (int p = 0; p < pause; ++p) __builtin_amdgcn_s_sleep(100);
+                keep = keep + x[3] + x[7] + x[11];
+                continue;
+            }
 #pragma unroll
             for (int T = 0; T < 16; ++T) {
                 const int off = kMode == 0 ? j * 256 + 4 * g + T * 16 : T * 256 + lane * 4;
@@ -77,6 +90,19 @@ int main() {
     }
     // fewer workgroups (one per CU, one per 2, 4, 8, 32 CUs): how long ONE wave's burst takes when the memory
     // system is not saturated — the latency-bound floor of a burst
-    for (int grid : {256, 128, 64, 32, 8}) run<0>(x, y, items / 8, mp, 0, sink, grid);
+    for (int grid : {256, 128, 64, 32, 8}) {
+        run<0>(x, y, items / 8, mp, 0, sink, grid);
+        run<1>(x, y, items / 8, mp, 0, sink, grid);
+    }
+    // the kernel's regime: every wave pauses between bursts (it computes), so the memory system is not saturated and a
+    // burst's duration is what the wave waits for: rows against tile-contiguous
+    for (int pause : {1, 2, 4, 8}) {
+        run<0>(x, y, items, mp, pause, sink);
+        run<1>(x, y, items, mp, pause, sink);
+    }
+    for (int pause : {0, 2, 4, 6, 8}) {
+        run<2>(x, y, items, mp, pause, sink);
+        run<3>(x, y, items, mp, pause, sink);
+    }
     return 0;
 }
