@@ -112,20 +112,20 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             f32x4 xh[16];
             float rstd;
             layer_wide_v4<kStagesL5>(pipe, acc, dout,
-                                     BwdHook{turn, ws + ba.L.xhat[4] + sp * kHidden + 4 * g,
+                                     BwdHook{turn, ws + ba.L.xhat[4] + tile_lane_base(sp, g),
                                              ws + ba.L.rstd[4] + sp, xh, rstd});
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
                 layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
-                                    ws + ba.L.dy[L] + sp * kHidden + 4 * g, gb + L * 2 * kHidden, turn, ba.inv_n);
+                                    ws + ba.L.dy[L] + tile_lane_base(sp, g), gb + L * 2 * kHidden, turn, ba.inv_n);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 layer_wide<kStagesHidden>(pipe, acc, act,
-                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + sp * kHidden + 4 * g,
+                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g),
                                                   ws + ba.L.rstd[L - 1] + sp, xh, rstd});
             }
-            layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + sp * kHidden + 4 * g,
+            layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + tile_lane_base(sp, g),
                                 gb, turn, ba.inv_n);
         }
     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
         asm volatile("" : "+v"(v));
         return v;
     };
-    const uint32_t row_off = (uint32_t)(j * kHidden + 4 * g);          // floats, in a [16][256] tile
+    const uint32_t row_off = (uint32_t)tile_lane_word(j, g);           // floats, in a tile-major [16][256] tile
     const uint32_t out_off = (uint32_t)(j * kOutPad + 4 * g);          // floats, in a [16][64] tile
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c   (uniform)
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                 rstd = (ws_stat + ba.L.rstd[4])[lane_word(j)];
                 const uint32_t ro = lane_word(row_off);
 #pragma unroll
-                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow + ro + T * 16);
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow + ro + T * kTileT);
             }
             float unscale;
             {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                     rstd = (ws_stat + ba.L.rstd[L - 1])[lane_word(j)];
                     const uint32_t ro = lane_word(row_off);
 #pragma unroll
-                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);
+                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * kTileT);
                 }
                 // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
                 // workgroup's maximum) the weight-gradient kernel's
@@ -448,11 +448,11 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
               : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_kernel, kBwdLdsBytes, device,
                                                 &done_data);
     if (rc) return rc;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_kernel, 2 * ShapeHid::kTileBytes, device,
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad);
     if (rc) return rc;
     static unsigned done_wgrad_h = 0;
-    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, 2 * ShapeHid::kTileBytes, device,
+    rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad_h);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;
@@ -467,9 +467,9 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     const int wgrad_jobs = 6;
     const bool wgrad_half = half;
     if (wgrad_half)
-        hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+        hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
     else
-        hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), 2 * ShapeHid::kTileBytes, st, ba);
+        hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
     hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(shape_of(a)) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
                        0, st, ba);
     return nerf_common::check_hip(hipGetLastError(), "render_backward launch");

@@ -42,7 +42,7 @@ struct GammaBetaTurn {
 // retires them only after a whole stage of MFMAs.)
 struct BwdHook {
     GammaBetaTurn& turn;
-    const float* xhat_row;      // this lane's 4 features of tile 0 in its sample's row
+    const float* xhat_row;      // this lane's 4 features of register tile 0 (tile-major rows: nerf_device.h)
     const float* rstd_ptr;
     f32x4 (&xh)[16];
     float& rstd;
@@ -50,7 +50,7 @@ struct BwdHook {
         turn(t);
         if (t == 1) {
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * 16);
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
             rstd = *rstd_ptr;
         }
     }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             dy[r] = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
             act[4 * T + r] = dy[r];
         }
-        *(f32x4*)(dy_row + T * 16) = dy;
+        *(f32x4*)(dy_row + T * kTileT) = dy;
     }
 }
 
@@ -409,11 +409,47 @@ __device__ __forceinline__ f32x16 mfma_bf(const bf8& a, const bf8& b, const f32x
 // ---------------------------------------------------------------------------------------------
 constexpr int kRingStep = 16;                    // samples per ring slot = one MFMA k-step
 constexpr int kRingSlots = 4;
+// A 256-wide operand arrives TILE-MAJOR (nerf_device.h): a k-step's 16 KiB are 16 register tiles T of 1 KiB, each
+// 64 chunks of 16 bytes (4 features of one sample) in the order [g][sample], and a DMA piece is one tile.  Which chunk
+// a DMA lane fetches is a per-lane global offset, so the order of the chunks INSIDE the LDS copy of a piece is free;
+// it is [s & 3][s >> 2][g] — word (s & 3) * 64 + (s >> 2) * 16 + (f & 15) — for two reasons:
+//  * a lane reads samples 8 kk + jj, jj = 0..7, of feature tiles X = 0..3 (lane = feature 32 X + i): with samples s,
+//    s + 1, s + 2, s + 3 exactly 64 words apart all 32 reads are (one lane base per half jj >> 2) + a multiple of 64
+//    words, ds_read2st64_b32's immediate offsets.  With the samples 16 words apart the reads needed a base per X:
+//    28 more v_add in a loop of 836 instructions that is issue-bound at one wave per SIMD — the kernel 4 % slower.
+//  * lanes i < 16 read tile 2 X and lanes i >= 16 tile 2 X + 1 at the same offset inside the tile, which are the same
+//    ds_read_b32 banks ((word address) % 32, per 32-lane half): a 2-way conflict on every read (measured: 6 %).
+//    ODD tiles are therefore SAMPLE-SWIZZLED on their way in — the chunk of sample s holds sample s ^ 4 — which
+//    moves them 16 banks from their even neighbours.  (Padding the odd tiles by 64 bytes instead does the same for
+//    the banks, but DMA pieces that are no longer 1 KiB-aligned in LDS made the kernel 9 % slower.)
+// A lane's read of (sample 8 kk + jj, feature 32 X + i) is word
+//   X * 512 + (i >> 4) * 256 + (jj & 3) * 64 + ((2 kk + (jj >> 2)) ^ (i >> 4)) * 16 + (i & 15).
+// Narrow operands (the 96 encoded inputs, the 64 padded outputs) are row-major [16][W] and copied as they are.
+template <int W>
+struct SlotLayout {
+    static constexpr bool kTiled = W == kHidden;
+    static constexpr int kPieces = kRingStep * W * 4 / 1024;
+    static constexpr int kBytes = kPieces * 1024;
+    // word offset of (sample 8 kk + jj, feature 32 X + i) = lane(kk, i, jj >> 2) + step(jj, X)
+    __device__ static constexpr int lane(int kk, int i, int hi_jj) {
+        return kTiled ? (i >> 4) * 256 + ((2 * kk + hi_jj) ^ (i >> 4)) * 16 + (i & 15) : (8 * kk + 4 * hi_jj) * W + i;
+    }
+    __device__ static constexpr int step(int jj, int X) { return kTiled ? (jj & 3) * 64 + X * 512 : (jj & 3) * W + 32 * X; }
+};
+struct OperandRows {          // a lane's view of one operand of one slot: rows[jj >> 2] + step(jj, X)
+    const float* rows[2];
+};
+template <class L>
+__device__ __forceinline__ OperandRows operand_rows(const char* region, int kk, int i, int X0) {
+    const float* r = (const float*)region + L::step(0, X0);
+    return OperandRows{{r + L::lane(kk, i, 0), r + L::lane(kk, i, 1)}};
+}
 constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 KiB (hidden shape)
-static_assert(kRingSlots * kRingSlotBytes == 2 * ShapeHid::kTileBytes, "same LDS as the two-buffer form");
 
-// N (<= 4) consecutive 1 KiB pieces: global (uniform base + lane * 16 + k KiB) -> LDS (base + k KiB)
-template <int N>
+// N (<= 4) consecutive 1 KiB pieces, the first an EVEN one: global (uniform base + k KiB + this lane's 16 bytes)
+// -> LDS (base + k KiB + lane * 16).  kTiled: LDS chunk `lane` = (s & 3, s >> 2, g) takes the tile's chunk (g, s) —
+// of sample s ^ 4 in odd pieces.
+template <int N, bool kTiled>
 __device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
     static_assert(N >= 1 && N <= 4, "immediate offsets reach 3 KiB");
     const uint64_t base_u = (uint64_t)(uintptr_t)src;
@@ -421,30 +457,39 @@ __device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
     const uint64_t sbase = ((uint64_t)hi << 32) | lo;
     const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+    const int sample = 4 * ((lane >> 2) & 3) + (lane >> 4);               // of LDS chunk `lane`
+    const int chunk_even = kTiled ? (lane & 3) * 16 + sample : lane;
+    const int chunk_odd = kTiled ? chunk_even ^ 4 : lane;
     uint32_t m0_saved;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 2\n\t"
         "global_load_lds_dwordx4 %1, %3\n\t"
-        ".if %c4 > 1\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t.endif\n\t"
+        ".if %c4 > 1\n\tglobal_load_lds_dwordx4 %5, %3 offset:1024\n\t.endif\n\t"
         ".if %c4 > 2\n\tglobal_load_lds_dwordx4 %1, %3 offset:2048\n\t.endif\n\t"
-        ".if %c4 > 3\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t.endif\n\t"
+        ".if %c4 > 3\n\tglobal_load_lds_dwordx4 %5, %3 offset:3072\n\t.endif\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(m0_saved)
-        : "v"(lane * 16), "s"(d), "s"(sbase), "n"(N)
+        : "v"(chunk_even * 16), "s"(d), "s"(sbase), "n"(N), "v"(chunk_odd * 16)
         : "memory");
 }
 
 // DMA instructions every wave issues per k-step (the same count on every wave: the hand-over's
-// vmcnt is an immediate).  dY rows are kOutW floats, X rows kInW: both regions are contiguous.
+// vmcnt is an immediate).  A k-step of dY is 16 kOutW contiguous floats in memory, of X 16 kInW (row-major or
+// tile-major: the same 1 KiB pieces either way).
 template <class Sh>
 struct RingPlan {
-    static constexpr int kDyPieces = kRingStep * Sh::kOutW * 4 / 1024;    // 16 / 16 / 4
-    static constexpr int kXPieces = kRingStep * Sh::kInW * 4 / 1024;      // 6 / 16 / 16
+    typedef SlotLayout<Sh::kOutW> Dy;
+    typedef SlotLayout<Sh::kInW> X;
+    static constexpr int kDyPieces = Dy::kPieces;                         // 16 / 16 / 4
+    static constexpr int kXPieces = X::kPieces;                           // 6 / 16 / 16
     static constexpr int kDyPerWave = (kDyPieces + 3) / 4, kXPerWave = (kXPieces + 3) / 4;
     static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
-    static constexpr int kXOffset = kRingStep * Sh::kOutW * 4;            // X behind dY in the slot
+    static constexpr int kXOffset = Dy::kBytes;                           // X behind dY in the slot
+    static_assert(Dy::kBytes + X::kBytes <= kRingSlotBytes, "a k-step must fit its slot");
+    static_assert((!Dy::kTiled || kDyPieces % 4 == 0) && (!X::kTiled || kXPieces % 4 == 0),
+                  "a wave's share of a tiled operand starts at an even tile");
 };
 
 // part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
@@ -459,7 +504,9 @@ __device__ __forceinline__ void ring_issue_part(const float* dy, const float* x,
     if (first + per > total) first = total - per;
     const char* src = kPart == 0 ? (const char*)(dy + sample0 * Sh::kOutW) : (const char*)(x + sample0 * Sh::kInW);
     char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
-    ring_dma<per>(src + first * 1024, dst + first * 1024, lane);
+    constexpr bool tiled = kPart == 0 ? P::Dy::kTiled : P::X::kTiled;
+    static_assert(!tiled || per % 2 == 0, "first piece of a wave even");
+    ring_dma<per, tiled>(src + first * 1024, dst + first * 1024, lane);
 }
 
 struct H2 {                   // an operand as f16 pairs: value = (h + l) / scale
@@ -585,28 +632,28 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
         constexpr bool has_next = !kLast;
         // one lane base per source; everything else in an address is a compile-time constant, so the
         // reads take immediate offsets (and pair up as ds_read2st64_b32) instead of one v_add each
-        const float* dyt = (const float*)slot_of(t) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
-        const float* dyn = (const float*)slot_of(t + 1) + (8 * kk) * Sh::kOutW + 32 * out0 + i;
-        const float* xn = (const float*)(slot_of(t + 1) + P::kXOffset) + (8 * kk) * Sh::kInW + 32 * in0 + i;
+        const OperandRows dyt = operand_rows<typename P::Dy>(slot_of(t), kk, i, out0);
+        const OperandRows dyn = operand_rows<typename P::Dy>(slot_of(t + 1), kk, i, out0);
+        const OperandRows xn = operand_rows<typename P::X>(slot_of(t + 1) + P::kXOffset, kk, i, in0);
         const bool issue_more = t + 3 < n_steps;
         char* fill = slot_of(t + 3);
 #pragma unroll
         for (int a = 0; a < Sh::kTo; ++a) {
             // the DMA of step t + 3: dY pieces behind the first slot's first MFMA, X pieces behind the second's
             const int na = a + 1 < Sh::kTo ? a + 1 : 0;
-            const float* asrc = a + 1 < Sh::kTo ? dyt : dyn;
+            const OperandRows& asrc = a + 1 < Sh::kTo ? dyt : dyn;
             float raw[1 + kBPerSlot][8];
             const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
             if (next_a) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc[jj * Sh::kOutW + 32 * na];
+                for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc.rows[jj >> 2][P::Dy::step(jj, na)];
             }
 #pragma unroll
             for (int q = 0; q < kBPerSlot; ++q) {
                 const int b = a * kBPerSlot + q;
                 if (b < Sh::kTi && has_next) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn[jj * Sh::kInW + 32 * b];
+                    for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn.rows[jj >> 2][P::X::step(jj, b)];
                 }
             }
             unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
@@ -777,19 +824,19 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
             }
         };
         {
-            const float* dyt = (const float*)slot_of(0);
-            const float* xt = (const float*)(slot_of(0) + P::kXOffset);
+            const OperandRows dyt = operand_rows<typename P::Dy>(slot_of(0), kk, i, out0);
+            const OperandRows xt = operand_rows<typename P::X>(slot_of(0) + P::kXOffset, kk, i, in0);
 #pragma unroll
             for (int b = 0; b < Sh::kTi; ++b) {
                 float v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = b_value(xt[(8 * kk + jj) * Sh::kInW + 32 * (in0 + b) + i], b);
+                for (int jj = 0; jj < 8; ++jj) v[jj] = b_value(xt.rows[jj >> 2][P::X::step(jj, b)], b);
                 b0[b] = convert(v);
             }
             float v[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                v[jj] = dyt[(8 * kk + jj) * Sh::kOutW + 32 * out0 + i];
+                v[jj] = dyt.rows[jj >> 2][P::Dy::step(jj, 0)];
                 bsum[0] += v[jj];
                 v[jj] *= a_scale;
             }

@@ -88,6 +88,28 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
     return t;
 }
 
+// Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the
+// [16 samples][256 features] tile of a wave is stored as its 16 register tiles T, 1 KiB each — so one vector-memory
+// instruction (a fixed T: lane (j, g) moves features 16 T + 4 g .. + 3 of sample j) touches ONE contiguous KiB
+// instead of sixteen 64-byte segments 1 KiB apart.  Same bytes, same 1 KiB LDS-DMA pieces for the weight gradient
+// (a 16-sample k-step is one 16 KiB tile either way) — but a CU's vector-memory path moves the contiguous form about
+// twice as fast when it, not HBM, is what a burst waits for (round 4: a wave's 33-operation burst 1.9 against 3.9 us
+// on an idle chip; the split-precision data gradient 0.74 against 0.86 ms).
+// Inside a register tile the order is the LANE order of the wave that owns it — lane 16 g + j (sample j, features
+// 4 g .. 4 g + 3) holds the 16 bytes at 16 * lane: [g][sample][4 features].  Which lane writes which 16 bytes of the
+// KiB is free, and it matters: the vector-memory path looks up four consecutive lanes at a time, and with sample-major
+// chunks ([sample][g]: a lane quad spans two 128-byte lines) the split-precision data gradient ran 0.74 ms, with the
+// quad's chunks 256 bytes apart 0.85 ms — hardly better than row-major rows (0.86 ms, a quad over four lines 1 KiB
+// apart).  The weight gradient's LDS-DMA re-orders the chunks of a piece on the way in (nerf_backward_common.h:
+// SlotLayout), so its LDS layout does not constrain this one.
+//   element (sample s of the tile, feature f) at  tile * 4096 + (f >> 4) * 256 + ((f & 15) >> 2) * 64 + s * 4 + (f & 3)
+constexpr int kTileFloats = 16 * kHidden;       // one 16-sample tile of a 256-wide row tensor
+constexpr int kTileT = 256;                     // floats between two register tiles T of a lane
+__host__ __device__ inline int tile_lane_word(int s, int g) { return g * 64 + s * 4; }
+__host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g) {      // this lane's f32x4 of register tile 0
+    return (sp >> 4) * kTileFloats + tile_lane_word((int)(sp & 15), g);
+}
+
 // The network's shape from an argument block (0 = the defaults 256 / 96), and what the LayerNorms need of it:
 // they divide their sums by hidden_size, not by the 256 features the kernels carry — the padded ones are exactly
 // zero before normalisation (nerf_layout.h: Shape) — and the two-pass variance takes their (0 - mean)^2 terms out.

@@ -35,7 +35,7 @@ struct LazyNorm {
     float rstd, shift;          // x_hat = fma(x, rstd, shift), shift = -mean * rstd
     const f32x4* gam;           // this lane group's gamma / beta in LDS: tile T at [T]
     const f32x4* bet;
-    float* save_row;            // training: this lane's x_hat row (tile T at + 16 T), else unused
+    float* save_row;            // training: this lane's x_hat of register tile 0 (tile T at + kTileT T), else unused
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -90,7 +90,7 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
             if (kTrain) xh[r] = (x[r] > 0.f && xh[r] <= n.shift) ? above : xh[r];
             x[r] = __builtin_fmaf(xh[r], ga[r], be[r]);
         }
-        if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
+        if (kTrain) *(f32x4*)(n.save_row + T * kTileT) = xh;
         return;
     }
     if (kPacked) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
             x[r] = __builtin_fmaxf(__builtin_fmaf(xh[r], ga[r], be[r]), 0.f);
         }
     }
-    if (kTrain) *(f32x4*)(n.save_row + T * 16) = xh;
+    if (kTrain) *(f32x4*)(n.save_row + T * kTileT) = xh;
 }
 template <bool kTrain, bool kPacked = false, int kOrder = kOrderNormRelu>
 __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int T) {

@@ -142,7 +142,7 @@ __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const fl
             if (kTrain) xh[r] = (act[4 * T + r] > 0.f && xh[r] <= shift) ? above : xh[r];
             act[4 * T + r] = __builtin_fmaf(xh[r], ga[r], be[r]);
         }
-        if (kTrain) *(f32x4*)(xhat_row + T * 16) = xh;
+        if (kTrain) *(f32x4*)(xhat_row + T * kTileT) = xh;
     }
     if (kTrain && g == 0) {
         *rstd_p = rstd;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_kernel(const LegacyKer
             float pos_act[64];
             encode_position(ray, t0, la, g, pos_act);
             // training: lane-relative bases of this sample's saved rows (+ the tensor's offset)
-            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;
+            float* const xrow = kTrain ? ws + tile_lane_base(sp, g) : nullptr;      // (tile-major rows)
             float* const stat = kTrain ? ws + sp : nullptr;
             if (kTrain) {
                 if (g == 0) *(f32x4*)(ws + ka.save.comp + sp * 4) = f32x4{0.f, 0.f, dist, 0.f};   // (not live across the MLP)
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 return r;
             };
             // training: lane-relative bases of this sample's saved rows (+ the tensor's offset)
-            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;
+            float* const xrow = kTrain ? ws + tile_lane_base(sp, g) : nullptr;      // (tile-major rows)
             float* const stat = kTrain ? ws + sp : nullptr;
             f32x4 X[16], Y[16];                   // a layer's input tiles (B operands) / its accumulators, in turn
             {

@@ -84,7 +84,7 @@ struct LegacyHook {
         turn(t);
         if (t == 1) {
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * 16);
+            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
             rstd = *rstd_ptr;
             shift = *shift_ptr;
         }
@@ -151,7 +151,7 @@ __device__ __forceinline__ void relu_layer_norm_bwd(const float* gamma_l, int g,
             dy[r] = xh[T][r] > shift ? da : 0.f;
             act[4 * T + r] = dy[r];
         }
-        *(f32x4*)(dy_row + T * 16) = dy;
+        *(f32x4*)(dy_row + T * kTileT) = dy;
     }
 }
 
@@ -188,8 +188,16 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;
         const int64_t sp = tile * 16 + j;
-        const float* const xbase = ws + sp * kHidden + 4 * g;         // + L.xhat[l]: this lane's a_hat row
-        float* const dybase = ba.rows + sp * kHidden + 4 * g;              // + L.dy[l]
+        // rows as (this tile's base: wave-uniform, SGPRs) + (the lane's 32-bit offset inside a tile): the register
+        // tiles T lie 1 KiB apart, beyond the 4 KiB an instruction offset reaches — per-lane 64-bit pointers would
+        // need four bases per tensor (nerf_backward.hip: nerf_bwd_data_h_kernel has the longer story)
+        const float* const xbase = ws + tile * kTileFloats;           // + L.xhat[l]: this tile's a_hat
+        float* const dybase = ba.rows + tile * kTileFloats;           // + L.dy[l]
+        const uint32_t row_off = (uint32_t)tile_lane_word(j, g);
+        auto lane_word = [](uint32_t v) {                             // (taken at every use: keeps the offset 32-bit)
+            asm volatile("" : "+v"(v));
+            return v;
+        };
         const float* const stat = ws + sp;                            // + L.rstd[l] / L.shift[l]
         // dL/d(density, r, g, b) of this sample: k slots (g 0, r 0..3) of BOTH head stages (the transposed
         // head images carry zeros in the slots that are not theirs; lane groups 1..3 read zero columns)
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
         f32x4 xh[16];
         float rstd, shift;
 #pragma unroll
-        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * 16);
+        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + lane_word(row_off) + T * kTileT);
         rstd = stat[ba.L.rstd[9]];
         shift = stat[ba.L.shift[9]];
         // ---- color head: dX'_9 = Wc^T d(color) ----
@@ -217,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_kernel(const LBwd
             const int last = phase == 0 ? 8 : 0;
 #pragma unroll 1
             for (; l >= last; --l) {
-                relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l],
+                relu_layer_norm_bwd(gamma + l * kHidden, g, j, acc, act, xh, rstd, shift, dybase + ba.L.dy[l] + lane_word(row_off),
                                     gb + l * 2 * kHidden, turn);
                 if (l == 0) break;
                 const int ln = l - 1;
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 layer_wide<16>(pipe, acc, act,
-                               LegacyHook{turn, xbase + ba.L.xhat[ln], stat + ba.L.rstd[ln], stat + ba.L.shift[ln], xh,
+                               LegacyHook{turn, xbase + ba.L.xhat[ln] + lane_word(row_off), stat + ba.L.rstd[ln], stat + ba.L.shift[ln], xh,
                                           rstd, shift});
             }
             if (phase == 0) {
@@ -286,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;
         const int64_t sp = tile * 16 + j;
-        const float* const xbase = ws + sp * kHidden + 4 * g;
-        float* const dybase = ba.rows + sp * kHidden + 4 * g;
+        const float* const xbase = ws + tile_lane_base(sp, g);
+        float* const dybase = ba.rows + tile_lane_base(sp, g);
         const float* const stat = ws + sp;
         // dL/d(density, r, g, b) on lane group 0 (zeros elsewhere), then a_hat / 1/std / shift of L9: 18 loads
         // that fly under the two stages of the color head
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
         f32x4 xh[16];
         float rstd, shift, unscale;
 #pragma unroll
-        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * 16);
+        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * kTileT);
         rstd = stat[ba.L.rstd[9]];
         shift = stat[ba.L.shift[9]];
         {
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
                 // the next LayerNorm backward's saved tile: 18 loads behind the 16 saves above (+ the density
                 // gradient, which joins L8's product in the same accumulators: same row, same scale)
 #pragma unroll
-                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + T * 16);
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + T * kTileT);
                 rstd = stat[ba.L.rstd[l - 1]];
                 shift = stat[ba.L.shift[l - 1]];
                 ddens = ba.rows[ba.L.dy5 + sp * kOutPad];

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
-            float* const xrow = kTrain ? ws + sp * kHidden + 4 * g : nullptr;     // + ka.save.xhat[L]
+            float* const xrow = kTrain ? ws + tile_lane_base(sp, g) : nullptr;     // + ka.save.xhat[L] (tile-major)
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
             LazyNorm norm;

@@ -79,6 +79,7 @@ def scan(path):
     valu_vgpr, valu_sgpr = {}, {}    # register -> clock of the last VALU write
     m0_write = -100
     vmem = []                   # vector-memory instructions in text order: (is LDS-DMA, inside asm)
+    no_fallthrough = False      # the previous instruction was an unconditional branch
     for ln, raw in enumerate(open(path).read().splitlines(), 1):
         s = raw.strip()
         m = re.match(r"^(_Z\S+):", s)
@@ -90,12 +91,17 @@ def scan(path):
         if s.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if not s or s.startswith((";", ".")):
+        label = re.match(r"^(\.?[A-Za-z_][\w.$]*):", s)
+        if label:                # a label: other paths join here, keep the state (conservative) ...
+            if no_fallthrough:   # ... unless the text above cannot fall into it (it ended in s_branch): the vector-memory
+                vmem = []        # history of whoever jumps here is not the text above (R6 then has nothing to count until
+                no_fallthrough = False        # the block has issued operations of its own)
             continue
-        if s.endswith(":"):      # a label: other paths join here, keep the state (conservative)
+        if not s or s.startswith((";", ".")):
             continue
         op = s.split()[0]
         ops = _operands(s)
+        no_fallthrough = op in ("s_branch", "s_endpgm", "s_setpc_b64")
         if op == "s_nop":
             ws += int(ops[0]) + 1
             continue

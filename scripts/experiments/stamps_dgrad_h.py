@@ -40,8 +40,9 @@ struct StampHook {
 VARIANTS = {
     # timing-only variants (wrong results): what the phases wait for
     "nostores": [("        *(f32x4*)(dy_row + T * 16) = dy;", "        if (kScaled) asm volatile(\"\" :: \"v\"(dy)); else *(f32x4*)(dy_row + T * 16) = dy;")],
-    "noloads": [("                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + T * 16);\n                rstd = ws[ba.L.rstd[L - 1] + sp];",
-                 "                for (int T = 0; T < 16; ++T) { xh[T] = f32x4{0.5f, -0.25f, 0.125f, 1.0f}; asm volatile(\"\" : \"+v\"(xh[T])); }\n                rstd = 1.0f; asm volatile(\"\" : \"+v\"(rstd));")],
+    "noloads": [("                    rstd = (ws_stat + ba.L.rstd[L - 1])[lane_word(j)];", "                    rstd = 1.0f; asm volatile(\"\" : \"+v\"(rstd));"),
+                ("                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);",
+                 "                    for (int T = 0; T < 16; ++T) { xh[T] = f32x4{0.5f, -0.25f, 0.125f, 1.0f} * (float)ro; asm volatile(\"\" : \"+v\"(xh[T])); }")],
     "nonote": [("                note_max(wmax + L, amax, lane);", "")],
     # no weight stream: the LDS-DMA of every stage is skipped (the ring keeps whatever it held; hand-over waits and
     # barriers stay) — what the data gradient's own loads and saves cost when they do not share the CU's vector-memory
@@ -52,21 +53,6 @@ VARIANTS = {
 
 def patch(src, variant=None):
     s = open(src).read()
-    if variant:
-        common = os.path.join(os.path.dirname(src), "nerf_backward_common.h")
-        device = os.path.join(os.path.dirname(src), "nerf_device.h")
-        c, dv = open(common).read(), open(device).read()
-        for name in variant.split("+"):
-            for old, new in VARIANTS[name]:
-                if old in s:
-                    s = s.replace(old, new)
-                elif old in c:
-                    c = c.replace(old, new)
-                else:
-                    assert old in dv, (name, old)
-                    dv = dv.replace(old, new)
-        open(device, "w").write(dv)
-        open(common, "w").write(c)
     s = s.replace("constexpr int kYoungerL5 = 17, kYoungerHidden = 33;",
                   "constexpr int kYoungerL5 = 17, kYoungerHidden = 33;" + STAMP_MACRO)
     head, kern = s.split("__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel", 1)
@@ -82,8 +68,15 @@ def patch(src, variant=None):
     uint64_t* const stamp_buf = (uint64_t*)(ba.dymax + (size_t)kMaxDataGrid * 8) + ((blockIdx.x / (gridDim.x / 2)) * 4 + wave) * 256;
     uint32_t stamp_off = 0;
 ''', 1)
-    kern = kern.replace("            const int64_t sp = tile * 16 + j;\n            f32x4 dout[4];",
-                        "            const int64_t sp = tile * 16 + j;\n            STAMP();\n            f32x4 dout[4];", 1)
+    assert kern.count("            f32x4 dout[4];\n") == 1
+    kern = kern.replace("            f32x4 dout[4];\n", "            STAMP();\n            f32x4 dout[4];\n", 1)
+    # finer: the 17 loads issued | row maximum + note_max | split
+    anchor = "                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);\n                }\n"
+    assert kern.count(anchor) == 1
+    kern = kern.replace(anchor, anchor + "                STAMP();\n")
+    anchor = "                note_max(wmax + L, amax, lane);\n"
+    assert kern.count(anchor) == 1
+    kern = kern.replace(anchor, anchor + "                STAMP();\n")
     kern = kern.replace("                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});",
                         "                STAMP();\n                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});\n                STAMP();")
     kern = kern.replace("                if (L == 0) break;", "                STAMP();\n                if (L == 0) break;")
@@ -94,6 +87,21 @@ def patch(src, variant=None):
     s = s.replace("(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float);",
                   "(size_t)kMaxDataGrid * (kGbFloats + 8)) * sizeof(float) + 8 * 256 * 8;")
     assert s.count("STAMP()") >= 8
+    if variant:
+        common = os.path.join(os.path.dirname(src), "nerf_backward_common.h")
+        device = os.path.join(os.path.dirname(src), "nerf_device.h")
+        c, dv = open(common).read(), open(device).read()
+        for name in variant.split("+"):
+            for old, new in VARIANTS[name]:
+                if old in s:
+                    s = s.replace(old, new)
+                elif old in c:
+                    c = c.replace(old, new)
+                else:
+                    assert old in dv, (name, old)
+                    dv = dv.replace(old, new)
+        open(device, "w").write(dv)
+        open(common, "w").write(c)
     if variant and ("noloads" in variant or "nostores" in variant):
         n = 33 - (17 if "noloads" in variant else 0) - (16 if "nostores" in variant else 0)
         s = s.replace("kYoungerHidden = 33;", f"kYoungerHidden = {n};")
@@ -127,11 +135,10 @@ def main():
         ((rgb - tgt.unsqueeze(1)) ** 2).mean().backward()
     torch.cuda.synchronize()
     raw = model._scratch_buf.view(torch.int64)[-8 * 256:].cpu().view(8, 256)
-    per_item = 1 + 2 + 4 * 8 + 1
     # item | L5: loop start, loop end | L = 4..1: LN end, loop start, ho1, ho2, ho3, ho8, loop end (+1: see below) | L0: LN end
     names = ["item", "L5 start", "L5 end"]
     for L in (4, 3, 2, 1):
-        names += [f"L{L} LN", f"L{L} split", f"L{L} ho1", f"L{L} ho2", f"L{L} ho3", f"L{L} ho8", f"L{L} end", None]
+        names += [f"L{L} LN", f"L{L} loads", f"L{L} max", f"L{L} split", f"L{L} ho1", f"L{L} ho2", f"L{L} ho3", f"L{L} ho8", f"L{L} end", None]
     names = [x for x in names if x is not None] + ["L0 LN"]
     per_item = len(names)
     import statistics
@@ -148,11 +155,11 @@ def main():
                 phase.setdefault(key, []).append(seg[i] - seg[i - 1])
     print(f"variant {os.environ.get('STAMP_VARIANT') or 'base'}: {len(items)} items of 8 waves (2 workgroups of one CU); "
           f"median item {statistics.median(items):.0f} cycles")
-    for key in ("LN", "split", "ho1", "ho2", "ho3", "ho8", "end", "L5 start", "L5 end", "L0 LN", "next item"):
+    for key in ("LN", "loads", "max", "split", "ho1", "ho2", "ho3", "ho8", "end", "L5 start", "L5 end", "L0 LN", "next item"):
         v = phase.get(key, [0])
         print(f"  {key:>9}: median {statistics.median(v):7.0f}  min {min(v):7.0f}  max {max(v):7.0f} cycles")
     print("(s_memtime ticks = shader cycles; hidden layers L4..L1 pooled: LN = LayerNorm backward incl. the 16 dY stores;"
-          " split = 17 x_hat loads issued + row maximum + f16 split; ho1/2/3/8 = hand-over of stage 1/2/3/8; end = loop end)")
+          " loads = the 17 x_hat loads issued; max = row maximum + note_max; split = the f16 split; ho1/2/3/8 = hand-over of stage 1/2/3/8; end = loop end)")
 
 
 if __name__ == "__main__":

@@ -56,10 +56,22 @@ def layer0_feature_order():
     return torch.tensor(order, dtype=torch.int64)
 
 
+def _row_major(workspace, lay, offset, width):
+    """The [mp, width] rows of one saved tensor.  Narrow tensors are stored like that; the 256-wide ones (x_hat, dY)
+    are TILE-MAJOR (nerf_device.h: tile_lane_base): a wave's 16 samples as [16 register tiles T][g][sample][4 features],
+    i.e. element (sample s, feature f) of tile n at n * 4096 + (f >> 4) * 256 + ((f & 15) >> 2) * 64 + s * 4 + (f & 3)."""
+    mp = lay["mp"]
+    flat = workspace[offset:offset + mp * width]
+    if width != HIDDEN:
+        return flat.view(mp, width)
+    tiles = flat.view(mp // 16, 16, 4, 16, 4)                # [n][T][g][s][r]
+    return tiles.permute(0, 3, 1, 2, 4).reshape(mp, HIDDEN)  # -> [n][s][T][g][r]
+
+
 def _rows(workspace, lay, offset, width, n_rays, num_samples):
     """[mp, width] rows -> [n_rays, S-1, width] (padded ray slots and samples dropped)."""
     chunks, mp = lay["chunks"], lay["mp"]
-    rows = workspace[offset:offset + mp * width].view(mp // (chunks * 16), chunks * 16, width)
+    rows = _row_major(workspace, lay, offset, width).view(mp // (chunks * 16), chunks * 16, width)
     return rows[:n_rays, :num_samples - 1]
 
 
@@ -116,7 +128,7 @@ def legacy_train_layout(n_rays, num_samples):
 
 def _legacy_rows(workspace, lay, offset, width, n_rays, num_samples):
     chunks, mp = lay["chunks"], lay["mp"]
-    rows = workspace[offset:offset + mp * width].view(mp // (chunks * 16), chunks * 16, width)
+    rows = _row_major(workspace, lay, offset, width).view(mp // (chunks * 16), chunks * 16, width)
     return rows[:n_rays, :num_samples]
 
 
