@@ -233,7 +233,22 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
                 layer_norm_relu_bwd<true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
                                           const_cast<float*>(ws_rows) + ba.L.dy[L] + lane_word(row_off), gb + L * 2 * kHidden,
                                           turn, ba.inv_n, unscale);
-                if (L == 0) break;                // dy[0] feeds only the weight gradient
+                if (L == 0) {
+                    // dy[0] feeds only the weight gradient, whose f16 pairs need ONE scale for the batch: a BOUND on
+                    // this sample's largest |dy_0| from the two scalars at hand, folded into the workgroup's maximum.
+                    // (The true maximum would take a pass over the 64 registers, and every place such a pass can go
+                    // makes the allocator spill 270-700 B inside the loops: 0.73 -> 1.05-1.29 ms.)
+                    //   |dz| <= |acc| unscale <= 2^21 C unscale   (B operands < 2^13, weights x 2^8, C = max column
+                    //                                               sum of |W_1|: the accumulator cannot exceed it)
+                    //   |dy| <= (|g dz| + |m1| + |x_hat| |m2|) / std <= 18 max|gamma| max|dz| / std
+                    //                                              (|m1|, |m2| <= max|g dz|; |x_hat| < 16)
+                    // K0 = 18 2^21 max|gamma_0| C with 1 % for rounding comes from the pack kernel.  The bound
+                    // overestimates by ~2^8: the batch's largest |dy_0| enters the weight gradient near 2^4 instead
+                    // of 2^12 — no overflow possible, elements down to 2^-7 of it keep all 22 bits, smaller ones
+                    // lose low bits that are below 2^-29 of the largest element.
+                    note_max(wmax + 0, rstd * unscale * a.packed[kBoundsOffset], lane);
+                    break;
+                }
                 // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above (1/std first: its
                 // address is the one thing here that is not a row offset), all of them younger than the two stages
                 // this layer's loop opens first
@@ -313,9 +328,8 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) 
                                               small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
                                               kSlabB + (job + 1) * kHidden, job + 1);
     } else if (job == 4) {
-        // layer 0 (the smallest job) stays on bf16 triples: recording the batch maximum of dy[0] in the
-        // data-gradient kernel costs that kernel 250-700 B of spills per lane, whichever way it is written
-        wgrad_body_ring<ShapeL0, kInputRaw, false>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
+        // layer 0: the scale comes from the data gradient's BOUND on |dy_0| (see there), not from a maximum
+        wgrad_body_ring<ShapeL0, kInputRaw, true>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, 0);
     } else {
         wgrad_body_ring<ShapeL5, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
                                              kSlabW5, kSlabB + 5 * kHidden, 5);

@@ -73,7 +73,13 @@ constexpr int kHSmallOffset = kHBlobOffset + kBlobFloats;
 //   pair i of a stage = in tile 8 * half + i; element (lane (row, kg), jj) of its slabs
 //   = 2^kWScaleLog2 * W[32 m + 16 (jj >> 2) + 4 kg + (jj & 3)][16 (8 half + i) + row]
 constexpr int kBwdHBlobOffset = kHSmallOffset + kSmallFloats;
-constexpr int kPackedFloats = kBwdHBlobOffset + kBwdBlobFloats;
+constexpr int kImageFloats = kBwdHBlobOffset + kBwdBlobFloats;          // the six images above
+// ... followed by four floats of per-launch constants derived from the weights:
+//   [0] K0 = 18 * 2^21 * max|gamma_0| * max_f sum_out |W_1[out][f]| * 1.01: with it the split-precision data gradient
+//       bounds a sample's |dL/dy_0| from two scalars it holds (nerf_backward.hip: nerf_bwd_data_h_kernel) — the
+//       layer-0 weight-gradient job's f16 scale; [1..3] unused
+constexpr int kBoundsOffset = kImageFloats;
+constexpr int kPackedFloats = kImageFloats + 4;
 
 // Network shape at run time (include/nerf_hip.h: hidden / enc_inputs / num_outputs of the argument blocks): the kernels always compute the compiled-in
 // 256 / 96 / 64 widths; a narrower network (hidden_size H <= 256, encoding_size with S = enc / 2 <= 16 scales,

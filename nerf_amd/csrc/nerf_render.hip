@@ -468,8 +468,27 @@ struct PackArgs {
 };
 
 __global__ void nerf_pack_kernel(const PackArgs pa) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // the bounds block (nerf_layout.h: kBoundsOffset): thread f = input feature f of layer 1
+        __shared__ float col[256], gam[256];
+        const int f = threadIdx.x;
+        float c = 0.f;
+        for (int out = 0; out < kHidden; ++out) c += __builtin_fabsf(pa.wh(1, out, f));
+        col[f] = c;
+        gam[f] = __builtin_fabsf(pa.vec(2, f));
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (f < w) {
+                col[f] = __builtin_fmaxf(col[f], col[f + w]);
+                gam[f] = __builtin_fmaxf(gam[f], gam[f + w]);
+            }
+            __syncthreads();
+        }
+        if (f < 4) pa.packed[kBoundsOffset + f] = f == 0 ? 18.0f * 2097152.0f * 1.01f * gam[0] * col[0] : 0.f;
+        return;
+    }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kPackedFloats) return;
+    if (e >= kImageFloats) return;
     float v = 0.f;
     if (e < kBlobFloats) {
         const int stage = e / kStageFloats;
@@ -655,7 +674,7 @@ int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t en
         pa.p[i] = params[i];
     }
     pa.packed = packed;
-    const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads;
+    const int threads = 256, blocks = (kImageFloats + threads - 1) / threads + 1;     // + the bounds block
     hipLaunchKernelGGL(nerf_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, pa);
     return nerf_common::check_hip(hipGetLastError(), "pack_weights launch");
 }
