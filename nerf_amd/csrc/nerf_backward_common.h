@@ -534,6 +534,18 @@ struct WgradJob {
     int data_grid;
     int dymax_stride;
 };
+// "1 MFMA, the slot's raw LDS reads (at most), then 1 MFMA + 6 VALU" as one scheduling pipeline with its own sync id
+template <int kSync, int kMfmas, int kReads>
+__device__ __forceinline__ void mfma_valu_pattern() {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, kSync);
+    __builtin_amdgcn_sched_group_barrier(0x100, kReads, kSync);
+#pragma unroll
+    for (int m = 1; m < kMfmas; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, kSync);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, kSync);
+    }
+}
+
 // kInput: what an X row holds — kInputRaw: the layer's input itself (encoded features);
 // kInputAffineRelu: the previous layer's saved x_hat, input = relu(gamma x_hat + beta) (the main network:
 // Linear -> LayerNorm -> ReLU); kInputAffine: input = gamma x_hat + beta (the legacy network: Linear -> ReLU ->
@@ -635,11 +647,22 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
         const OperandRows dyt = operand_rows<typename P::Dy>(slot_of(t), kk, i, out0);
         const OperandRows dyn = operand_rows<typename P::Dy>(slot_of(t + 1), kk, i, out0);
         const OperandRows xn = operand_rows<typename P::X>(slot_of(t + 1) + P::kXOffset, kk, i, in0);
-        const bool issue_more = t + 3 < n_steps;
+        // The DMA of step t + 3 goes out UNCONDITIONALLY: behind the last step it re-fetches the last step into a
+        // slot nobody reads any more.  (A run-time branch around the issue ends the scheduling region of the slot it
+        // sits in: the first two slots of every step came out as 12 MFMAs | branch | DMA | all conversions — 850-920
+        // cycles against 520-540 for the two slots without a DMA; scripts/experiments/stamps_wgrad_h.py.)
+        const int64_t t_fill = t + 3 < n_steps ? t + 3 : n_steps - 1;
         char* fill = slot_of(t + 3);
 #pragma unroll
         for (int a = 0; a < Sh::kTo; ++a) {
-            // the DMA of step t + 3: dY pieces behind the first slot's first MFMA, X pieces behind the second's
+            // the DMA of step t + 3: dY pieces in front of the first slot, X pieces in front of the second (f16 form: in
+            // FRONT of the slot's LDS reads and scheduling region — inside the region the volatile asm splits it, and
+            // the half behind it carries the conversions without MFMAs to hide under; bf16 form: pinned behind the
+            // slot's first MFMA)
+            if constexpr (kF16) {
+                if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
+                if (a == 1) ring_issue_part<Sh, 1>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
+            }
             const int na = a + 1 < Sh::kTo ? a + 1 : 0;
             const OperandRows& asrc = a + 1 < Sh::kTo ? dyt : dyn;
             float raw[1 + kBPerSlot][8];
@@ -672,10 +695,6 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     const int b = m / kPerProduct, tt = m % kPerProduct;
                     acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
                 }
-                if (a < 2 && issue_more) {
-                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                }
 #pragma unroll
                 for (int op = 0; op < 1 + kBPerSlot; ++op) {
                     const int bq = a * kBPerSlot + (op - 1);
@@ -697,12 +716,13 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     if (op == 0) an = r;
                     else bnext[bq] = r;
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8 * (1 + kBPerSlot), 0);     // the raw LDS reads (at most)
-#pragma unroll
-                for (int m = 1; m < kMfmas; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                // (one sync id per slot: with the DMA issue unconditional all slots of a step sit in ONE basic block, and
+                //  as one pipeline of 4 x 12 groups the scheduler gave up on the first slots)
+                switch (a) {
+                    case 0: mfma_valu_pattern<0, kMfmas, 8 * (1 + kBPerSlot)>(); break;
+                    case 1: mfma_valu_pattern<1, kMfmas, 8 * (1 + kBPerSlot)>(); break;
+                    case 2: mfma_valu_pattern<2, kMfmas, 8 * (1 + kBPerSlot)>(); break;
+                    default: mfma_valu_pattern<3, kMfmas, 8 * (1 + kBPerSlot)>(); break;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 continue;
@@ -718,10 +738,8 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (m == 0 && a < 2 && issue_more) {
-                    if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                    else ring_issue_part<Sh, 1>(dy, x, sample_begin + (t + 3) * kRingStep, fill, wave, lane);
-                }
+                if (m == 0 && a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
+                if (m == 0 && a == 1) ring_issue_part<Sh, 1>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
 #pragma unroll
                 for (int it = 0; it < kItems; ++it) {
                     if (kLead + it * (kMfmas - kLead) / kItems != m) continue;
@@ -795,8 +813,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
         }
         // hand-over: this wave's pieces of step t + 2 have landed (the kPerWave pieces of step t + 3,
         // issued above, may still fly), its LDS reads are done; behind the barrier every wave's are
-        if (issue_more) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(P::kPerWave) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(P::kPerWave) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -850,6 +867,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
         }
         k_step(more_steps, n_steps - 2, b0, b1);
         k_step(last_step, n_steps - 1, b1, b0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetches behind the last step
     }
 
     float* slab = ba.slab;

@@ -26,6 +26,20 @@ STAMP = r'''
 '''
 
 
+INNER = r'''
+// s_memtime stamps INSIDE the k-steps of workgroup 0, wave 0 (shader cycles): slots 6144.. of the stamp area
+#define ISTAMP()                                                                                          \
+    do {                                                                                                  \
+        if (inner_on && inner_off < 8u * 2040u) {                                                         \
+            uint64_t t_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, %2"       \
+                         : "=&s"(t_) : "s"(inner_buf), "s"(inner_off) : "memory");                        \
+            inner_off += 8u;                                                                              \
+        }                                                                                                 \
+    } while (0)
+'''
+
+
 def patch(csrc):
     p = os.path.join(csrc, "nerf_backward_common.h")
     s = open(p).read()
@@ -34,14 +48,20 @@ def patch(csrc):
         nonlocal s
         assert s.count(a) == 1, (a, s.count(a))
         s = s.replace(a, b)
-    rep("struct WgradJob {\n", STAMP + "struct WgradJob {\n    uint64_t* stamps;                             // EXPERIMENT: 8 slots of this workgroup\n")
+    rep("struct WgradJob {\n", STAMP + INNER + "struct WgradJob {\n    uint64_t* stamps;                             // EXPERIMENT: 8 slots of this workgroup\n")
     rep("    int out0, in0;                                // first 32-wide tile of this wave\n",
         "    WSTAMP(0);\n    if (wave == 0 && ba.stamps != nullptr) {\n        uint32_t hw, xcc;\n"
         "        asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\\n\\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\" : \"=s\"(hw), \"=s\"(xcc));\n"
         "        const uint64_t id = ((uint64_t)xcc << 32) | hw;\n"
         "        asm volatile(\"s_store_dwordx2 %0, %1, 56\" :: \"s\"(id), \"s\"(ba.stamps) : \"memory\");\n    }\n"
         "    int out0, in0;                                // first 32-wide tile of this wave\n")
-    rep("    f32x16 acc[Sh::kTo][Sh::kTi];\n", "    WSTAMP(1);\n    f32x16 acc[Sh::kTo][Sh::kTi];\n")
+    rep("    f32x16 acc[Sh::kTo][Sh::kTi];\n", "    WSTAMP(1);\n    const bool inner_on = wave == 0 && blockIdx.x == 0 && ba.stamps != nullptr;\n"
+        "    uint64_t* const inner_buf = ba.stamps + 6144;\n    uint32_t inner_off = 0;\n    f32x16 acc[Sh::kTo][Sh::kTi];\n")
+    # one stamp in front of every slot of a k-step, in front of the hand-over wait, behind it, behind the barrier
+    rep("            const Operand& ac = at[a & 1];\n            Operand& an = at[(a & 1) ^ 1];\n            __builtin_amdgcn_sched_barrier(0);\n",
+        "            const Operand& ac = at[a & 1];\n            Operand& an = at[(a & 1) ^ 1];\n            __builtin_amdgcn_sched_barrier(0);\n            ISTAMP();\n            __builtin_amdgcn_sched_barrier(0);\n")
+    rep("        asm volatile(\"s_waitcnt vmcnt(%c0) lgkmcnt(0)\" ::\"n\"(P::kPerWave) : \"memory\");\n        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n    };",
+        "        ISTAMP();\n        asm volatile(\"s_waitcnt vmcnt(%c0) lgkmcnt(0)\" ::\"n\"(P::kPerWave) : \"memory\");\n        ISTAMP();\n        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        ISTAMP();\n    };")
     rep("        Operand b0[Sh::kTi], b1[Sh::kTi];\n", "        WSTAMP(2);\n        Operand b0[Sh::kTi], b1[Sh::kTi];\n")
     rep("    float* slab = ba.slab;\n    const int col = lane & 31, half = lane >> 5;\n",
         "    WSTAMP(3);\n    float* slab = ba.slab;\n    const int col = lane & 31, half = lane >> 5;\n")
@@ -124,6 +144,17 @@ def main():
           f"its CU: median {statistics.median(gaps):.1f} us, max {max(gaps):.1f} us")
     ends = sorted(us(max(e for _, e, _ in lst) - t0) for lst in cus.values())
     print(f"  last exit per CU: min {ends[0]:.1f}, median {ends[len(ends) // 2]:.1f}, max {ends[-1]:.1f} us")
+    inner = [int(v) for v in raw.reshape(-1)[6144:6144 + 2040].tolist() if int(v) != 0]
+    per = 4 + 3                                          # slots a = 0..3, wait, barrier, after
+    steps = [inner[k * per:(k + 1) * per + 1] for k in range(8, min(120, len(inner) // per - 1))]
+    if steps:
+        names = ["slot 0 (12 MFMAs)", "slot 1", "slot 2", "slot 3", "hand-over wait (vmcnt / lgkmcnt)", "barrier", "to the next step's first slot"]
+        print(f"  inside the k-steps of workgroup 0, wave 0 ({len(steps)} steady-state steps; s_memtime ticks):")
+        for k, nm in enumerate(names):
+            v = [st[k + 1] - st[k] for st in steps]
+            print(f"    {nm:36s} median {statistics.median(v):7.0f}  min {min(v):6.0f}  max {max(v):6.0f}")
+        v = [st[-1] - st[0] for st in steps]
+        print(f"    {'whole step':36s} median {statistics.median(v):7.0f}  min {min(v):6.0f}  max {max(v):6.0f}")
     order = sorted(cus.items(), key=lambda kv: kv[1][0][0])[:3]
     for cu, lst in order:
         print("   CU", cu, " ".join(f"[wg {i} ({'hidden' if i < 4 * splits else 'L0' if i < 5 * splits else 'L5'}) {us(s - t0):.1f}..{us(e - t0):.1f}]" for s, e, i in lst))
