@@ -468,12 +468,27 @@ struct PackArgs {
 };
 
 __global__ void nerf_pack_kernel(const PackArgs pa) {
-    if (blockIdx.x == gridDim.x - 1) {
-        // the bounds block (nerf_layout.h: kBoundsOffset): thread f = input feature f of layer 1
+    if (blockIdx.x == 0) {
+        // the bounds block (nerf_layout.h: kBoundsOffset; first, so that it runs beside the others): thread f = input
+        // feature f of layer 1
         __shared__ float col[256], gam[256];
         const int f = threadIdx.x;
+        // (loads at clamped addresses, masked afterwards: behind a bounds test per element the compiler emits a branch
+        //  and a full wait per load — 256 dependent round trips, 50 us)
+        const float* const w1 = pa.p[4];
+        const int H = pa.hidden, fc = f < H ? f : H - 1;
         float c = 0.f;
-        for (int out = 0; out < kHidden; ++out) c += __builtin_fabsf(pa.wh(1, out, f));
+        for (int o0 = 0; o0 < kHidden; o0 += 64) {
+            float v[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const int o = o0 + k < H ? o0 + k : H - 1;
+                v[k] = w1[o * H + fc];
+            }
+#pragma unroll
+            for (int k = 0; k < 64; ++k) c += o0 + k < H ? __builtin_fabsf(v[k]) : 0.f;
+        }
+        if (f >= H) c = 0.f;
         col[f] = c;
         gam[f] = __builtin_fabsf(pa.vec(2, f));
         __syncthreads();
@@ -487,7 +502,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         if (f < 4) pa.packed[kBoundsOffset + f] = f == 0 ? 18.0f * 2097152.0f * 1.01f * gam[0] * col[0] : 0.f;
         return;
     }
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     if (e >= kImageFloats) return;
     float v = 0.f;
     if (e < kBlobFloats) {
