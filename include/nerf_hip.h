@@ -71,6 +71,8 @@ size_t nerf_hip_packed_bytes(void);
  *   prediction_heads.{0.weight[H,E], 0.bias[H], 1.weight[H], 1.bias[H], 3.weight[H,H], 3.bias,
  *   4.*, 6.*, 7.*, 9.*, 10.*, 12.*, 13.*, 15.weight[num_outputs,H], 15.bias[num_outputs]}
  * Must be called again whenever the parameters change (once per optimiser step).
+ * The image ends with four floats of constants derived from the weights; [0] lets the split-precision
+ * backward bound |dL/dy| of layer 0 per sample (the f16 scale of that layer's weight gradient).
  */
 int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t enc_inputs, int32_t num_outputs,
                           float* packed, void* stream);
