@@ -653,21 +653,13 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
         // cycles against 520-540 for the two slots without a DMA; scripts/experiments/stamps_wgrad_h.py.)
         const int64_t t_fill = t + 3 < n_steps ? t + 3 : n_steps - 1;
         char* fill = slot_of(t + 3);
-#pragma unroll
-        for (int a = 0; a < Sh::kTo; ++a) {
-            // the DMA of step t + 3: dY pieces in front of the first slot, X pieces in front of the second (f16 form: in
-            // FRONT of the slot's LDS reads and scheduling region — inside the region the volatile asm splits it, and
-            // the half behind it carries the conversions without MFMAs to hide under; bf16 form: pinned behind the
-            // slot's first MFMA)
-            if constexpr (kF16) {
-                if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
-                if (a == 1) ring_issue_part<Sh, 1>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
-            }
+        // the raw values slot a converts (A operand of slot a + 1, B operands of the next step): two register sets —
+        // the f16 form reads slot a + 1's in the middle of slot a, when slot a's own are dead (level 0 is done)
+        float raw2[2][1 + kBPerSlot][8];
+        auto read_raw = [&](int a, float (&raw)[1 + kBPerSlot][8]) {
             const int na = a + 1 < Sh::kTo ? a + 1 : 0;
             const OperandRows& asrc = a + 1 < Sh::kTo ? dyt : dyn;
-            float raw[1 + kBPerSlot][8];
-            const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
-            if (next_a) {
+            if (a + 1 < Sh::kTo || has_next) {
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) raw[0][jj] = asrc.rows[jj >> 2][P::Dy::step(jj, na)];
             }
@@ -679,6 +671,21 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     for (int jj = 0; jj < 8; ++jj) raw[1 + q][jj] = xn.rows[jj >> 2][P::X::step(jj, b)];
                 }
             }
+        };
+#pragma unroll
+        for (int a = 0; a < Sh::kTo; ++a) {
+            // the DMA of step t + 3: dY pieces in front of the first slot, X pieces in front of the second (f16 form: in
+            // FRONT of the slot's LDS reads and scheduling region — inside the region the volatile asm splits it, and
+            // the half behind it carries the conversions without MFMAs to hide under; bf16 form: pinned behind the
+            // slot's first MFMA)
+            if constexpr (kF16) {
+                if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
+                if (a == 1) ring_issue_part<Sh, 1>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
+            }
+            const int na = a + 1 < Sh::kTo ? a + 1 : 0;
+            float (&raw)[1 + kBPerSlot][8] = raw2[a & 1];
+            const bool next_a = a + 1 < Sh::kTo || has_next;       // compile-time per code instance
+            if (!kF16 || a == 0) read_raw(a, raw);
             unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
             u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
             h2 qh[1 + kBPerSlot][4], ql[1 + kBPerSlot][4];   // f16 form: pair p of the operand, hi / lo
@@ -686,43 +693,66 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
             Operand& an = at[(a & 1) ^ 1];
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (kF16) {
-                // f16 form: the slot's 3 kTi MFMAs and its conversions (4 dependent levels per value
-                // pair: scale, pkrtz, residual, pkrtz) handed to the scheduler as ONE region with the
-                // pattern "1 MFMA, then 6 VALU" — pinned value by value (as the bf16 form below does) each
-                // MFMA gap holds one dependent chain, which runs at 1.7x its issue time
+                // f16 form: the slot's 3 kTi MFMAs with its conversions PINNED between them, level by level: every
+                // value pair goes through four dependent levels (scale / affine, hi = pkrtz, two residuals, lo =
+                // pkrtz); the micro-operations are ordered level-major over all pairs of all the slot's operands, so
+                // neighbours are independent, and dealt out evenly over the MFMA gaps.  (Handed to the scheduler as
+                // a "1 MFMA, 6 VALU" pipeline, two of the four slots came out as 12 MFMAs | all conversions: only 38 %
+                // of the matrix pipe's busy cycles had a VALU instruction beside them — SQ_VALU_MFMA_COEXEC_CYCLES,
+                // profiles/r04_p_train_f16x3_wgrad_pmc.json.  Pinned pair by pair — one dependent chain per gap —
+                // a chain runs at 1.7x its issue time.)
+                constexpr int kOps = 1 + kBPerSlot;
+                constexpr int kMicro = kOps * 4 * 4;                  // operands x pairs x levels
+                float v0[kOps][4], v1[kOps][4];
+                h2 nh[kOps][4], nl[kOps][4];
+                auto active = [&](int op) {
+                    const int bq = a * kBPerSlot + (op - 1);
+                    if (op > 0) return bq < Sh::kTi && has_next;
+                    return next_a;
+                };
+                auto micro = [&](int idx) {
+                    const int level = idx / (kOps * 4), op = (idx % (kOps * 4)) / 4, pp = idx % 4;
+                    if (!active(op)) return;
+                    const int bq = a * kBPerSlot + (op - 1);
+                    if (level == 0) {
+                        float x0 = raw[op][2 * pp], x1 = raw[op][2 * pp + 1];
+                        if (op > 0) {
+                            x0 = b_value(x0, bq), x1 = b_value(x1, bq);
+                        } else {
+                            bsum[na] += x0;               // unscaled: the scaled value then dies in its split
+                            asm("" : "+v"(bsum[na]));     // (no v_pk_add_f32 with an op_sel swap: isa_scan rule R5)
+                            bsum[na] += x1;
+                            x0 *= a_scale, x1 *= a_scale;
+                        }
+                        v0[op][pp] = x0, v1[op][pp] = x1;
+                    } else if (level == 1) {
+                        nh[op][pp] = pack_rtz(v0[op][pp], v1[op][pp]);
+                    } else if (level == 2) {
+                        v0[op][pp] = residual<0>(v0[op][pp], nh[op][pp]);
+                        v1[op][pp] = residual<1>(v1[op][pp], nh[op][pp]);
+                    } else {
+                        nl[op][pp] = pack_rtz(v0[op][pp], v1[op][pp]);
+                        asm volatile("" : "+v"(nl[op][pp]));
+                    }
+                };
 #pragma unroll
                 for (int m = 0; m < kMfmas; ++m) {
                     const int b = m / kPerProduct, tt = m % kPerProduct;
                     acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int idx = m * kMicro / kMfmas; idx < (m + 1) * kMicro / kMfmas; ++idx) micro(idx);
+                    if (m == kMfmas / 2 && a + 1 < Sh::kTo) read_raw(a + 1, raw2[(a + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int op = 0; op < 1 + kBPerSlot; ++op) {
-                    const int bq = a * kBPerSlot + (op - 1);
-                    if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
-                    if (op == 0 && !next_a) continue;
-                    float v[8];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        if (op > 0) v[w] = b_value(raw[op][w], bq);
-                        else {
-                            bsum[na] += raw[op][w];       // unscaled: the scaled value then dies in its split
-                            asm("" : "+v"(bsum[na]));     // (keeps SLP from pairing the adds into v_pk_add_f32
-                                                          //  with an op_sel swap: isa_hazards.py rule R5)
-                            v[w] = raw[op][w] * a_scale;
-                        }
-                    }
+                for (int op = 0; op < kOps; ++op) {
+                    if (!active(op)) continue;
                     Operand r;
-                    split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, r.h, r.l);
+                    r.h = join8(nh[op][0], nh[op][1], nh[op][2], nh[op][3]);
+                    r.l = join8(nl[op][0], nl[op][1], nl[op][2], nl[op][3]);
                     if (op == 0) an = r;
-                    else bnext[bq] = r;
-                }
-                // (one sync id per slot: with the DMA issue unconditional all slots of a step sit in ONE basic block, and
-                //  as one pipeline of 4 x 12 groups the scheduler gave up on the first slots)
-                switch (a) {
-                    case 0: mfma_valu_pattern<0, kMfmas, 8 * (1 + kBPerSlot)>(); break;
-                    case 1: mfma_valu_pattern<1, kMfmas, 8 * (1 + kBPerSlot)>(); break;
-                    case 2: mfma_valu_pattern<2, kMfmas, 8 * (1 + kBPerSlot)>(); break;
-                    default: mfma_valu_pattern<3, kMfmas, 8 * (1 + kBPerSlot)>(); break;
+                    else bnext[a * kBPerSlot + (op - 1)] = r;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 continue;

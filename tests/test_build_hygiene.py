@@ -158,13 +158,13 @@ def test_loader_refuses_a_library_older_than_its_sources(tmp_path):
 SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses between two MFMAs)
     "nerf_bwd_data_kernel": (56, 1),
     "nerf_bwd_data_h_kernel": (24, 0),
-    "nerf_wgrad_h_kernel": (24, 0),
+    "nerf_wgrad_h_kernel": (12, 0),
     "nerf_legacy_fwd_kernelILb1E": (76, 0),
     "nerf_legacy_fwd_h_kernelILb0E": (60, 0),
     "nerf_legacy_fwd_h_kernelILb1E": (228, 7),
     "nerf_legacy_bwd_data_kernel": (272, 0),
     "nerf_legacy_bwd_data_h_kernel": (96, 1),
-    "nerf_legacy_wgrad_h_kernel": (24, 0),
+    "nerf_legacy_wgrad_h_kernel": (12, 0),
 }
 
 
