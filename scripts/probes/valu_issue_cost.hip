@@ -36,6 +36,17 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define I_MASKAND(c) asm volatile("v_sub_u32 %0, 0, %1\n\tv_ashrrev_i32 %0, 31, %0\n\tv_and_b32 %0, %0, %2" : "=&v"(q[c]) : "v"(r[c]), "v"(k0));
 #define I_MULCLAMP(c) asm volatile("v_mul_f32_e64 %0, %1, %2 clamp\n\tv_mul_f32 %0, %0, %3" : "=&v"(q[c]) : "v"(r[c]), "v"(k0), "v"(k1));
 
+// round 4: the candidates for cheaper conversions
+#define I_PKMUL(c) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p2[c]) : "v"(kk));
+#define I_PKADD(c) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p2[c]) : "v"(kk));
+#define I_MIXLO16(c) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(r[c]) : "v"(q[c]));
+#define I_MIXHI16(c) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r[c]) : "v"(q[c]), "v"(k0));
+// one value PAIR of the weight gradient's dY conversion as it ships (2 add, 2 mul, pkrtz, 2 fma_mix, pkrtz) and with
+// packed scale / bias add + f16-result residuals (pk_add, pk_mul, pkrtz, mixlo, mixhi)
+#define I_PAIR8(c) I_ADD(c) I_ADD((c + 1) & 15) I_MUL(c) I_MUL((c + 1) & 15) I_PKRTZ(c) I_MIX(c) I_MIXHI((c + 1) & 15) I_PKRTZ((c + 1) & 15)
+#define I_PAIR5(c) I_PKADD(c) I_PKMUL(c) I_PKRTZ(c) I_MIXLO16(c) I_MIXHI16(c)
+#define I_PAIR6(c) I_PKADD(c) I_PKMUL(c) I_PKRTZ(c) I_MIX(c) I_MIXHI((c + 1) & 15) I_PKRTZ((c + 1) & 15)
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int kForm>
@@ -131,6 +142,13 @@ __global__ __launch_bounds__(256, 1) void gaps(float* out, unsigned long long* c
                 if (kForm == 8) { I_PKRTZ(c) }
                 if (kForm == 9) { I_MIX(c) }
                 if (kForm == 7) { I_PERM(c) }
+                if (kForm == 20) { I_PKMUL(c) }
+                if (kForm == 21) { I_PKADD(c) }
+                if (kForm == 22) { I_MIXLO16(c) }
+                if (kForm == 23) { I_MIXHI16(c) }
+                if (kForm == 24) { I_PAIR8(c) }           // (kFill counts PAIRS for forms 24..26)
+                if (kForm == 25) { I_PAIR5(c) }
+                if (kForm == 26) { I_PAIR6(c) }
             }
         }
         REP16(KEEP)
@@ -184,5 +202,12 @@ int main() {
     run_gap<8, 2>(out, cyc, "v_cvt_pkrtz"); run_gap<8, 4>(out, cyc, "v_cvt_pkrtz"); run_gap<8, 6>(out, cyc, "v_cvt_pkrtz");
     run_gap<9, 2>(out, cyc, "v_fma_mix"); run_gap<9, 4>(out, cyc, "v_fma_mix"); run_gap<9, 6>(out, cyc, "v_fma_mix");
     run_gap<7, 2>(out, cyc, "v_perm_b32"); run_gap<7, 4>(out, cyc, "v_perm_b32"); run_gap<7, 6>(out, cyc, "v_perm_b32");
+    run_gap<20, 2>(out, cyc, "v_pk_mul_f32 bcast"); run_gap<20, 4>(out, cyc, "v_pk_mul_f32 bcast"); run_gap<20, 6>(out, cyc, "v_pk_mul_f32 bcast");
+    run_gap<21, 2>(out, cyc, "v_pk_add_f32"); run_gap<21, 4>(out, cyc, "v_pk_add_f32"); run_gap<21, 6>(out, cyc, "v_pk_add_f32");
+    run_gap<22, 2>(out, cyc, "v_fma_mixlo_f16"); run_gap<22, 4>(out, cyc, "v_fma_mixlo_f16"); run_gap<22, 6>(out, cyc, "v_fma_mixlo_f16");
+    run_gap<23, 2>(out, cyc, "v_fma_mixhi_f16"); run_gap<23, 4>(out, cyc, "v_fma_mixhi_f16"); run_gap<23, 6>(out, cyc, "v_fma_mixhi_f16");
+    // whole conversion pairs per MFMA gap (the kernel: 0.75 pairs per gap = 6 VALU)
+    run_gap<24, 1>(out, cyc, "pair, 8 VALU (ships)"); run_gap<25, 1>(out, cyc, "pair, 5 VALU (pk + mixlo/hi)");
+    run_gap<26, 1>(out, cyc, "pair, 6 VALU (pk + mix + pkrtz)");
     return 0;
 }
