@@ -39,9 +39,9 @@ struct StampHook {
 
 VARIANTS = {
     # timing-only variants (wrong results): what the phases wait for
-    "nostores": [("        *(f32x4*)(dy_row + T * 16) = dy;", "        if (kScaled) asm volatile(\"\" :: \"v\"(dy)); else *(f32x4*)(dy_row + T * 16) = dy;")],
+    "nostores": [("        *(f32x4*)(dy_row + T * kTileT) = dy;", "        if (kScaled) asm volatile(\"\" :: \"v\"(dy)); else *(f32x4*)(dy_row + T * kTileT) = dy;")],
     "noloads": [("                    rstd = (ws_stat + ba.L.rstd[L - 1])[lane_word(j)];", "                    rstd = 1.0f; asm volatile(\"\" : \"+v\"(rstd));"),
-                ("                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);",
+                ("                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * kTileT);",
                  "                    for (int T = 0; T < 16; ++T) { xh[T] = f32x4{0.5f, -0.25f, 0.125f, 1.0f} * (float)ro; asm volatile(\"\" : \"+v\"(xh[T])); }")],
     "nonote": [("                note_max(wmax + L, amax, lane);", "")],
     # no weight stream: the LDS-DMA of every stage is skipped (the ring keeps whatever it held; hand-over waits and
@@ -71,7 +71,7 @@ def patch(src, variant=None):
     assert kern.count("            f32x4 dout[4];\n") == 1
     kern = kern.replace("            f32x4 dout[4];\n", "            STAMP();\n            f32x4 dout[4];\n", 1)
     # finer: the 17 loads issued | row maximum + note_max | split
-    anchor = "                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * 16);\n                }\n"
+    anchor = "                    for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * kTileT);\n                }\n"
     assert kern.count(anchor) == 1
     kern = kern.replace(anchor, anchor + "                STAMP();\n")
     anchor = "                note_max(wmax + L, amax, lane);\n"
@@ -79,7 +79,8 @@ def patch(src, variant=None):
     kern = kern.replace(anchor, anchor + "                STAMP();\n")
     kern = kern.replace("                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});",
                         "                STAMP();\n                layer_wide_h<2, kYoungerL5>(pipe, acc, bh, bl, TurnHook{turn});\n                STAMP();")
-    kern = kern.replace("                if (L == 0) break;", "                STAMP();\n                if (L == 0) break;")
+    assert kern.count("                if (L == 0) {\n") == 1
+    kern = kern.replace("                if (L == 0) {\n", "                STAMP();\n                if (L == 0) {\n")
     kern = kern.replace("                layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, TurnHook{turn});",
                         "                STAMP();\n                layer_wide_h<8, kYoungerHidden>(pipe, acc, bh, bl, StampHook{turn, stamp_on, stamp_buf, stamp_off});\n                STAMP();")
     kern = kern.replace("    if (threadIdx.x < 8) ba.dymax[", "    asm volatile(\"s_dcache_wb\" ::: \"memory\");\n    if (threadIdx.x < 8) ba.dymax[")
