@@ -6,6 +6,9 @@
 //   mode 0  rows: lane (j, g) touches 16 B at [sample j][16 T + 4 g] — sixteen 64-byte segments 1 KiB apart per
 //           instruction (the product's row-major workspace)
 //   mode 1  tile-contiguous: each instruction touches 1 KiB (what a tile-major workspace would give)
+//   mode 4  as mode 1 through buffer instructions (one descriptor per tensor, lane offset in a VGPR, tile base in an SGPR)
+//   mode 5  as mode 1 with 8-byte accesses (twice the instructions): is a burst paid per instruction or per byte?
+//   mode 6  as mode 1, the loads as LDS-DMA (global_load_lds_dwordx4) + ds_read_b128 instead of register loads
 //   pause   s_sleep units between the burst of one layer and the next (0: back to back; the kernel computes ~20 us)
 // Build: hipcc --offload-arch=gfx950 -O2 scripts/probes/dgrad_traffic.hip -o gpurun_out/dgrad_traffic
 #include <hip/hip_runtime.h>
@@ -30,6 +33,56 @@ __global__ __launch_bounds__(256, 2) void probe(const float* xhat, float* dy, in
             const float* src = xhat + (int64_t)L * mp * 256 + item * 16 * 256;
             float* dst = dy + (int64_t)L * mp * 256 + item * 16 * 256;
             f32x4 x[16];
+            if (kMode == 4) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xhat + (int64_t)L * mp * 256), 0, 0x7fffffff, 0x27000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (int64_t)L * mp * 256), 0, 0x7fffffff, 0x27000);
+                const int base = __builtin_amdgcn_readfirstlane((int)(item * 16 * 256 * 4));
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    x[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + T * 1024, base, 0));
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, x[T] + keep), rd, lane * 16 + T * 1024, base, 0);
+                keep = keep + x[3];
+                for (int p = 0; p < pause; ++p) __builtin_amdgcn_s_sleep(100);
+                continue;
+            }
+            if (kMode == 5) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 h[32];
+#pragma unroll
+                for (int T = 0; T < 32; ++T) h[T] = *(const f32x2*)(src + T * 128 + lane * 2);
+#pragma unroll
+                for (int T = 0; T < 32; ++T) *(f32x2*)(dst + T * 128 + lane * 2) = h[T] + f32x2{keep.x, keep.y};
+                keep.x += h[3].x;
+                for (int p = 0; p < pause; ++p) __builtin_amdgcn_s_sleep(100);
+                continue;
+            }
+            if (kMode == 6) {
+                // 16 KiB of this wave's LDS (4 waves x 16 KiB = 64 KiB of the 74 KiB block)
+                char* mine = smem + (threadIdx.x >> 6) * 16384;
+                const uint64_t sb = (uint64_t)(uintptr_t)src;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+                const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(mine + q * 4096));
+                    uint32_t saved;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\t"
+                                 "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved) : "v"(lane * 16 + q * 4096), "s"(d), "s"(sbase) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int T = 0; T < 16; ++T) x[T] = *(const f32x4*)(mine + T * 1024 + lane * 16);
+#pragma unroll
+                for (int T = 0; T < 16; ++T) *(f32x4*)(dst + T * 256 + lane * 4) = x[T] + keep;
+                keep = keep + x[3];
+                for (int p = 0; p < pause; ++p) __builtin_amdgcn_s_sleep(100);
+                continue;
+            }
             if (kMode >= 2) {
                 if (kMode == 3) __syncthreads();
 #pragma unroll
@@ -103,6 +156,20 @@ int main() {
     for (int pause : {0, 2, 4, 6, 8}) {
         run<2>(x, y, items, mp, pause, sink);
         run<3>(x, y, items, mp, pause, sink);
+    }
+    // round 4: other ways of moving the same contiguous KiB per instruction — one wave's burst on a quiet chip and in
+    // the kernel's regime
+    for (int grid : {256, 32, 8}) {
+        run<1>(x, y, items / 8, mp, 0, sink, grid);
+        run<4>(x, y, items / 8, mp, 0, sink, grid);
+        run<5>(x, y, items / 8, mp, 0, sink, grid);
+        run<6>(x, y, items / 8, mp, 0, sink, grid);
+    }
+    for (int pause : {0, 4}) {
+        run<1>(x, y, items, mp, pause, sink);
+        run<4>(x, y, items, mp, pause, sink);
+        run<5>(x, y, items, mp, pause, sink);
+        run<6>(x, y, items, mp, pause, sink);
     }
     return 0;
 }
