@@ -627,9 +627,9 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     constexpr int kPerProduct = kF16 ? 3 : 6;
     constexpr int kMfmas = kPerProduct * Sh::kTi;             // per slot
     constexpr int kLead = kMfmas / 6;
-    // conversion work items per operand — bf16: 8 values + 2 packing items; f16: 4 value pairs
-    // (scale / affine) + 4 pair splits (hi = pkrtz, two residuals, lo = pkrtz)
-    constexpr int kItemsPerOp = kF16 ? 8 : 10;
+    // conversion work items per operand of the bf16 form: 8 values + 2 packing items (the f16 form has its own
+    // micro-operations, below)
+    constexpr int kItemsPerOp = 10;
     constexpr int kItems = kItemsPerOp * (1 + kBPerSlot);
     typedef typename std::conditional<kF16, H2, Bf3>::type Operand;
     static_assert(Sh::kTo % 2 == 0, "the A operand sets ping-pong slot by slot");
@@ -688,7 +688,6 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
             if (!kF16 || a == 0) read_raw(a, raw);
             unsigned th[1 + kBPerSlot][8], tm[1 + kBPerSlot][8], tl[1 + kBPerSlot][8];
             u32x4 ph[1 + kBPerSlot], pm[1 + kBPerSlot], pl[1 + kBPerSlot];
-            h2 qh[1 + kBPerSlot][4], ql[1 + kBPerSlot][4];   // f16 form: pair p of the operand, hi / lo
             const Operand& ac = at[a & 1];
             Operand& an = at[(a & 1) ^ 1];
             __builtin_amdgcn_sched_barrier(0);
@@ -755,18 +754,15 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     else bnext[a * kBPerSlot + (op - 1)] = r;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                continue;
-            }
+            } else {
+            // bf16 form: every conversion instruction pinned to its MFMA gap (left alone, its longer chains were clumped
+            // in front of the MFMA batch)
 #pragma unroll
             for (int m = 0; m < kMfmas; ++m) {
                 const int b = m / kPerProduct, tt = m % kPerProduct;
-                if constexpr (kF16) {
-                    acc[a][b] = mfma_hw(tt == 2 ? ac.l : ac.h, tt == 1 ? bcur[b].l : bcur[b].h, acc[a][b]);
-                } else {
-                    const bf8& ta = tt == 5 ? ac.l : (tt == 2 || tt == 3 ? ac.m : ac.h);
-                    const bf8& tb = tt == 4 ? bcur[b].l : (tt == 1 || tt == 3 ? bcur[b].m : bcur[b].h);
-                    acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
-                }
+                const bf8& ta = tt == 5 ? ac.l : (tt == 2 || tt == 3 ? ac.m : ac.h);
+                const bf8& tb = tt == 4 ? bcur[b].l : (tt == 1 || tt == 3 ? bcur[b].m : bcur[b].h);
+                acc[a][b] = mfma_bf(ta, tb, acc[a][b]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (m == 0 && a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
                 if (m == 0 && a == 1) ring_issue_part<Sh, 1>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);
@@ -777,35 +773,6 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                     const int bq = a * kBPerSlot + (op - 1);
                     if (op > 0 && (bq >= Sh::kTi || !has_next)) continue;
                     if (op == 0 && !next_a) continue;
-                    if constexpr (kF16) {
-                        if (w < 4) {                  // values 2w, 2w + 1: scale (dY) or affine + ReLU (X)
-#pragma unroll
-                            for (int e2 = 0; e2 < 2; ++e2) {
-                                float val = raw[op][2 * w + e2];
-                                asm volatile("" : "+v"(val));
-                                if (op > 0) val = b_value(val, bq);
-                                else {
-                                    bsum[na] += val;
-                                    val *= a_scale;
-                                }
-                                asm volatile("" : "+v"(val));
-                                raw[op][2 * w + e2] = val;
-                            }
-                        } else {                      // pair w - 4: hi = pkrtz, residuals, lo = pkrtz
-                            const int pp = w - 4;
-                            const float v0 = raw[op][2 * pp], v1 = raw[op][2 * pp + 1];
-                            qh[op][pp] = pack_rtz(v0, v1);
-                            ql[op][pp] = pack_rtz(residual<0>(v0, qh[op][pp]), residual<1>(v1, qh[op][pp]));
-                            asm volatile("" : "+v"(ql[op][pp]));
-                            if (pp == 3) {
-                                Operand r;
-                                r.h = join8(qh[op][0], qh[op][1], qh[op][2], qh[op][3]);
-                                r.l = join8(ql[op][0], ql[op][1], ql[op][2], ql[op][3]);
-                                if (op == 0) an = r;
-                                else bnext[bq] = r;
-                            }
-                        }
-                    } else {
                     if (w < 8) {
                         float val = raw[op][w];
                         asm volatile("" : "+v"(val));
@@ -836,9 +803,9 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
                             else bnext[bq] = r;
                         }
                     }
-                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
         // hand-over: this wave's pieces of step t + 2 have landed (the kPerWave pieces of step t + 3,
