@@ -11,7 +11,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-__global__ __launch_bounds__(256, 1) void probe(const char* src, unsigned long long* cycles, int order, int iters, int wait_every) {
+__global__ __launch_bounds__(256) void probe(const char* src, unsigned long long* cycles, int order, int iters, int wait_every) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sample = 4 * ((lane >> 2) & 3) + (lane >> 4);
@@ -45,18 +45,19 @@ int main() {
     hipMemset(src, 1, (size_t)256 * 4 * 65536);
     hipMalloc(&cyc, 64);
     hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    for (int grid : {1, 256})
-        for (int wait_every : {16, 4})
-            for (int order = 0; order < 4; ++order) {
-                const int iters = 64;
-                probe<<<grid, 256, 65536>>>(src, cyc, order, iters, wait_every);
-                hipDeviceSynchronize();
-                probe<<<grid, 256, 65536>>>(src, cyc, order, iters, wait_every);
-                hipDeviceSynchronize();
-                unsigned long long c;
-                hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-                printf("workgroups %3d, vmcnt(0) every %2d, order %d: %7.1f ticks per DMA instruction (issue + its share of the wait)\n", grid,
-                       wait_every, order, (double)c / (iters * 16.0));
-            }
+    for (int waves : {4, 1})                       // waves per CU issuing at the same time
+        for (int grid : {1, 256})
+            for (int wait_every : {16, 4})
+                for (int order = 0; order < 4; ++order) {
+                    const int iters = 64;
+                    probe<<<grid, 64 * waves, 65536>>>(src, cyc, order, iters, wait_every);
+                    hipDeviceSynchronize();
+                    probe<<<grid, 64 * waves, 65536>>>(src, cyc, order, iters, wait_every);
+                    hipDeviceSynchronize();
+                    unsigned long long c;
+                    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+                    printf("waves per CU %d, workgroups %3d, vmcnt(0) every %2d, order %d: %7.1f ticks per DMA instruction (issue + its share of the wait)\n",
+                           waves, grid, wait_every, order, (double)c / (iters * 16.0));
+                }
     return 0;
 }
