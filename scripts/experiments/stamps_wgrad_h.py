@@ -57,6 +57,9 @@ def patch(csrc):
         "    int out0, in0;                                // first 32-wide tile of this wave\n")
     rep("    f32x16 acc[Sh::kTo][Sh::kTi];\n", "    WSTAMP(1);\n    const bool inner_on = wave == 0 && blockIdx.x == 0 && ba.stamps != nullptr;\n"
         "    uint64_t* const inner_buf = ba.stamps + 6144;\n    uint32_t inner_off = 0;\n    f32x16 acc[Sh::kTo][Sh::kTi];\n")
+    # around the dY half of the DMA issue (in front of slot 0)
+    rep("                if (a == 0) ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);\n                if (a == 1)",
+        "                if (a == 0) {\n                    ISTAMP();\n                    ring_issue_part<Sh, 0>(dy, x, sample_begin + t_fill * kRingStep, fill, wave, lane);\n                    ISTAMP();\n                }\n                if (a == 1)")
     # one stamp in front of every slot of a k-step, in front of the hand-over wait, behind it, behind the barrier
     rep("            const Operand& ac = at[a & 1];\n            Operand& an = at[(a & 1) ^ 1];\n            __builtin_amdgcn_sched_barrier(0);\n",
         "            const Operand& ac = at[a & 1];\n            Operand& an = at[(a & 1) ^ 1];\n            __builtin_amdgcn_sched_barrier(0);\n            ISTAMP();\n            __builtin_amdgcn_sched_barrier(0);\n")
@@ -145,14 +148,15 @@ def main():
     ends = sorted(us(max(e for _, e, _ in lst) - t0) for lst in cus.values())
     print(f"  last exit per CU: min {ends[0]:.1f}, median {ends[len(ends) // 2]:.1f}, max {ends[-1]:.1f} us")
     inner = [int(v) for v in raw.reshape(-1)[6144:6144 + 2040].tolist() if int(v) != 0]
-    per = 4 + 3                                          # slots a = 0..3, wait, barrier, after
+    per = 2 + 4 + 3                                      # DMA issue (2), slots a = 0..3, wait, barrier, after
     steps = [inner[k * per:(k + 1) * per + 1] for k in range(8, min(120, len(inner) // per - 1))]
     if steps:
-        names = ["slot 0 (12 MFMAs)", "slot 1", "slot 2", "slot 3", "hand-over wait (vmcnt / lgkmcnt)", "barrier", "to the next step's first slot"]
+        names = ["dY half of the DMA issue (4 instructions)", "raw LDS reads of slot 0 issued", "slot 0 (12 MFMAs; + the X half of the DMA issue at its end)", "slot 1",
+                 "slot 2", "slot 3", "hand-over wait (vmcnt / lgkmcnt)", "barrier", "barrier -> DMA issue of the next step (addresses)"]
         print(f"  inside the k-steps of workgroup 0, wave 0 ({len(steps)} steady-state steps; s_memtime ticks):")
         for k, nm in enumerate(names):
             v = [st[k + 1] - st[k] for st in steps]
-            print(f"    {nm:36s} median {statistics.median(v):7.0f}  min {min(v):6.0f}  max {max(v):6.0f}")
+            print(f"    {nm:60s} median {statistics.median(v):7.0f}  min {min(v):6.0f}  max {max(v):6.0f}")
         v = [st[-1] - st[0] for st in steps]
         print(f"    {'whole step':36s} median {statistics.median(v):7.0f}  min {min(v):6.0f}  max {max(v):6.0f}")
     order = sorted(cus.items(), key=lambda kv: kv[1][0][0])[:3]
