@@ -294,7 +294,16 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;
         const int64_t sp = tile * 16 + j;
-        const float* const xbase = ws + tile_lane_base(sp, g);
+        // a_hat tiles as (this tile's base: wave-uniform) + (the lane's 32-bit offset, taken at every use); the dY rows and
+        // the per-sample scalars keep their per-lane pointers.  Which of the three goes uniform was swept
+        // (NOTES.md R4: all three 180-208 B of scratch and 1.98 ms; this one 68 B, none inside the loops, 1.47 against
+        // 1.54 ms) — the allocator's answer to a source change in these 256-register kernels has to be measured.
+        const float* const xbase = ws + tile * kTileFloats;
+        const uint32_t row_off = (uint32_t)tile_lane_word(j, g);
+        auto lane_word = [](uint32_t v) {
+            asm volatile("" : "+v"(v));
+            return v;
+        };
         float* const dybase = ba.rows + tile_lane_base(sp, g);
         const float* const stat = ws + sp;
         // dL/d(density, r, g, b) on lane group 0 (zeros elsewhere), then a_hat / 1/std / shift of L9: 18 loads
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
         f32x4 xh[16];
         float rstd, shift, unscale;
 #pragma unroll
-        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + T * kTileT);
+        for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[9] + lane_word(row_off) + T * kTileT);
         rstd = stat[ba.L.rstd[9]];
         shift = stat[ba.L.shift[9]];
         {
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_bwd_data_h_kernel(const LB
                 // the next LayerNorm backward's saved tile: 18 loads behind the 16 saves above (+ the density
                 // gradient, which joins L8's product in the same accumulators: same row, same scale)
 #pragma unroll
-                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + T * kTileT);
+                for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xbase + ba.L.xhat[l - 1] + lane_word(row_off) + T * kTileT);
                 rstd = stat[ba.L.rstd[l - 1]];
                 shift = stat[ba.L.shift[l - 1]];
                 ddens = ba.rows[ba.L.dy5 + sp * kOutPad];

@@ -163,7 +163,7 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
     "nerf_legacy_fwd_h_kernelILb0E": (60, 0),
     "nerf_legacy_fwd_h_kernelILb1E": (228, 7),
     "nerf_legacy_bwd_data_kernel": (272, 0),
-    "nerf_legacy_bwd_data_h_kernel": (96, 1),
+    "nerf_legacy_bwd_data_h_kernel": (68, 0),
     "nerf_legacy_wgrad_h_kernel": (12, 0),
 }
 
