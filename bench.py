@@ -4,6 +4,15 @@
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (no launcher: bench.py starts the N ranks itself)
+
+Launch convention: under ``torch.distributed.run`` (WORLD_SIZE set) this process IS one rank.  A plain
+``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE becomes the launcher: before it makes any GPU call
+it starts ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free> bench.py <the same arguments>`` as a CHILD process (never an exec), lets the child's
+output through unchanged (rank 0's one JSON line) and exits with the child's code.  ``--dry-run`` walks the
+same launch + rendezvous + partition code over gloo without touching a GPU (the 8-rank form of the path can
+be rehearsed on any machine; a one-GPU box of this pool allows at most 6 processes on its card).
 
 One step = NeRF.render_image of the 800x800x128 frame (rays generated in-kernel from the pose,
 deterministic fenceposts, RGB + 50-class segmentation composited): the whole hot path, inputs
@@ -586,6 +595,95 @@ def shard_rows(rank, world):
     return product_shard_rows(IMAGE, rank, world)
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(gpus, argv):
+    """``python bench.py --gpus N`` outside torch.distributed.run: start the N ranks as a child process of this
+    one, which has made no GPU call (and makes none afterwards), with the driver's own launcher command line;
+    the child's stdout / stderr are inherited, so rank 0's JSON line is this command's output.  Returns the
+    child's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] --gpus {gpus} without WORLD_SIZE: starting the ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """The N > 1 line without a GPU: rendezvous over gloo, this rank's row block of the frame and its share of the
+    config-5 batch, one flat all-reduce of a gradient-sized buffer through the product's FlatGradientAllReduce,
+    MAX over ranks of a clock — every host-side step of the multi-GPU path, none of the kernels.  Rank 0 prints
+    one JSON line (value null: nothing was measured)."""
+    import torch.distributed as dist
+    from nerf_amd.parallel import FlatGradientAllReduce, shard_items
+    if world > 1:
+        dist.init_process_group("gloo")
+    rows = shard_rows(rank, world)
+    batch = shard_items(4096, rank, world)
+    params = [torch.nn.Parameter(torch.zeros(304438))]
+    params[0].grad = torch.full((304438,), float(rank + 1))
+    if world > 1:
+        FlatGradientAllReduce(params)(None, (batch[1] - batch[0]) / 4096.0)
+        mine = torch.tensor([rows[0], rows[1], batch[0], batch[1]], dtype=torch.int64)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+    else:
+        parts = [torch.tensor([rows[0], rows[1], batch[0], batch[1]])]
+    want = sum((r + 1) * (shard_items(4096, r, world)[1] - shard_items(4096, r, world)[0]) / 4096.0 for r in range(world))
+    reduced_ok = world == 1 or bool((params[0].grad - want).abs().max() < 1e-5)
+    if rank == 0:
+        blocks = [[int(v) for v in p.tolist()] for p in parts]
+        print(json.dumps({
+            "metric": "ray-samples/sec at 800x800x128", "value": None, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
+            "config": {"workload": "dry run: launch, rendezvous and partitions only; no GPU call, nothing measured",
+                       "rays_per_gpu": (rows[1] - rows[0]) * IMAGE, "rendezvous_backend": "gloo" if world > 1 else None,
+                       "row_blocks": [b[:2] for b in blocks], "collectives": "none"},
+            "train_step_dp": {"rays_per_rank": batch[1] - batch[0], "global_batch": 4096,
+                              "batch_blocks": [b[2:] for b in blocks], "gradient_bytes": 304438 * 4,
+                              "flat_all_reduce_matches_weighted_sum": reduced_ok}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def scaling_projection(model, dev, whole_ms, steps=3):
+    """ONE-GPU PROJECTION of the strong-scaling line (no multi-GPU hardware is reachable from this bench): for
+    N = 2, 4, 8 every one of the N row blocks of the frame is rendered on this GPU and timed; the projected
+    speed-up is the whole frame's time / the SLOWEST block's time — what N GPUs would reach if nothing but the
+    kernels mattered (inference has no collective; launch and barrier costs are not in it).  A projection, not
+    a measurement of N GPUs, and labelled so."""
+    cam_o, cam_r = look_at(CAMERA)
+    cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
+    out = {"kind": "projection from ONE GPU: whole-frame ms / slowest row-block ms; not a multi-GPU measurement",
+           "whole_frame_ms": whole_ms, "steps_per_block": steps}
+    with torch.no_grad():
+        for world in (2, 4, 8):
+            worst = 0.0
+            for r in range(world):
+                rows = shard_rows(r, world)
+                model.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES, row_begin=rows[0], row_end=rows[1])
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES, row_begin=rows[0], row_end=rows[1])
+                torch.cuda.synchronize(dev)
+                worst = max(worst, (time.perf_counter() - t0) / steps * 1e3)
+            out[str(world)] = {"slowest_block_ms": worst, "projected_speedup": whole_ms / worst,
+                               "projected_efficiency": whole_ms / worst / world}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -598,10 +696,23 @@ def main():
                     help="N > 1: if RCCL cannot initialise, rendezvous over gloo instead of failing "
                          "(the line then says rendezvous_backend gloo: no RCCL credit)")
     ap.add_argument("--precision", choices=("fp32", "f16x3"), default=os.environ.get("NERF_BENCH_PRECISION", "fp32"))
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch, rendezvous (gloo) and partitions only: no GPU call, nothing measured")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become it (before any GPU call; a child process, never an exec)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: start bench.py with "
+              f"--nproc-per-node {args.gpus}, or without a launcher (it starts its own ranks)", file=sys.stderr)
+        raise SystemExit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     backend = None
@@ -631,7 +742,6 @@ def main():
             print(f"[bench] nccl init failed ({exc}); --allow-gloo: barriers over gloo", file=sys.stderr)
             dist.init_process_group("gloo")
             backend = "gloo"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", device_index)
 
     from nerf_amd import NeRF, _lib
@@ -750,6 +860,7 @@ def main():
             line["legacy_train_step"] = legacy_train_step_timing(dev)
             line["legacy_train_step_f16x3"] = legacy_train_step_timing(dev, train_precision="f16x3")
             line["configs"] = baseline_configs(dev)
+            line["scaling_projection"] = scaling_projection(model, dev, m["elapsed"] / args.steps * 1e3)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if distributed:

@@ -58,3 +58,38 @@ def test_defaults_are_the_reference_arithmetic_and_the_one_frame_partition(monke
     assert bench.PRECISIONS["fp32"]["dtype"] == "f32"
     assert bench.physical_cores() >= 1
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
+
+
+def _bench(*argv, env=None, timeout=600):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          env=e, timeout=timeout)
+
+
+def test_plain_gpus_8_starts_its_own_eight_ranks_dry_run():
+    """``python bench.py --gpus 8`` with no launcher around it (the shape of the driver's one-GPU command) must not
+    die on first contact: it starts the eight ranks itself before any GPU call.  ``--dry-run`` walks launch,
+    rendezvous and partitions over gloo without a GPU, so the 8-rank form runs here: 100 rows = 80,000 rays of the
+    frame and 512 rays of the config-5 batch per rank, one JSON line from rank 0, exit code 0."""
+    run = _bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run")
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "starting the ranks" in run.stderr and "torch.distributed.run" in run.stderr
+    lines = [x for x in run.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["rays_per_gpu"] == 80000
+    assert line["config"]["row_blocks"] == [[100 * r, 100 * (r + 1)] for r in range(8)]
+    dp = line["train_step_dp"]
+    assert dp["rays_per_rank"] == 512 and dp["global_batch"] == 4096
+    assert dp["batch_blocks"] == [[512 * r, 512 * (r + 1)] for r in range(8)]
+    assert dp["gradient_bytes"] == 304438 * 4 and dp["flat_all_reduce_matches_weighted_sum"] is True
+
+
+def test_launcher_and_gpus_disagreeing_is_a_message_not_an_assert():
+    run = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert run.returncode == 2 and "WORLD_SIZE=2" in run.stderr and "AssertionError" not in run.stderr
+    one = _bench("--gpus", "1", "--dry-run")                     # N = 1: no launcher, no rendezvous
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["config"]["rays_per_gpu"] == 640000

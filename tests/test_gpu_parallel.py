@@ -222,6 +222,35 @@ def test_the_drivers_multi_gpu_bench_command_runs_as_a_rehearsal(tmp_path):
     assert dp["graph"]["ms_per_step"] > 0 and dp["graph"]["collective_and_optimiser_in_graph"] is False   # gloo: outside
 
 
+def test_plain_bench_gpus_n_starts_its_own_ranks(tmp_path):
+    """The OTHER launch form: ``python bench.py --gpus 4 --allow-gloo`` with no torch.distributed.run around it and no
+    WORLD_SIZE in the environment.  bench.py must start the ranks itself (a child launcher, before any GPU call of
+    its own), relay rank 0's one JSON line and the exit code.  Four ranks share this box's GPU (the pool allows at
+    most 6 processes on a card, so the 8-rank form is rehearsed without the GPU: tests/test_bench_contract.py);
+    the partitions are the N = 4 ones: 200 rows = 160,000 rays of the frame, 1024 rays of the config-5 batch."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--allow-gloo", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "starting the ranks" in run.stderr
+    lines = [x for x in run.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong"
+    assert line["config"]["rays_per_gpu"] == 160000 and line["config"]["collectives"] == "none"
+    assert line["config"]["rendezvous_backend"] == "gloo" and "rehearsal" in line["config"]
+    assert 0.5 * 2.2e8 <= line["value"] <= 1.2 * 2.3e8          # four ranks time-share ONE GPU: about one GPU's rate
+    assert line["weak_scaling"]["frames"] == 4
+    dp = line["train_step_dp"]
+    assert dp["rays_per_rank"] == 1024 and dp["global_batch"] == 4096 and dp["gradient_bytes"] == 304438 * 4
+    assert dp["replicas_identical"] is True and dp["parameters_finite"] is True
+
+
 def _rccl_single_rank_worker(rank, world, port, out_dir):
     """ONE rank on RCCL (backend "nccl"): the only form of the RCCL path a one-GPU box can run.  The collective is
     then a (trivial) stream-ordered RCCL launch — what matters here is that it, the scale in front of it and the
