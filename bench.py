@@ -147,10 +147,31 @@ def cpu_baseline_run(threads, budget_s, max_rows=32):
     return done * SAMPLES / dt, done, dt
 
 
+def cpu_baseline_small(threads):
+    """BASELINE config 1 / BASELINE.md section 4 "100x100x64 always": the WHOLE tiny_nerf-sized frame through the
+    oracle (max_chunk_size 1024, no_grad, focal 112, the bench pose) on `threads` host threads."""
+    from oracle import nerf_oracle as O
+    torch.set_num_threads(threads)
+    params = O.init_params(seed=0)
+    cfg = dict(O.default_config(), focal_length=112.0)
+    cam_o, cam_r = look_at(CAMERA)
+    rays_o, rays_d = O.image_rays(cam_o, cam_r, 100, 100, 112.0)
+    with torch.no_grad():
+        O.render_rays(params, cfg, rays_o[:1024], rays_d[:1024], 64)          # warm-up
+        t0 = time.perf_counter()
+        for a, b in zip(torch.split(rays_o, 1024), torch.split(rays_d, 1024)):
+            O.render_rays(params, cfg, a, b, 64)
+        dt = time.perf_counter() - t0
+    return {"workload": "100x100 frame, 64 samples/ray, whole frame (BASELINE config 1), max_chunk_size 1024",
+            "cores": threads, "seconds": dt, "value": 100 * 100 * 64 / dt, "unit": "ray-samples/s"}
+
+
 def cpu_baseline():
     """The oracle on this box's host cores, twice: on min(16, CPUs) threads (the CPU share a one-GPU
     slot of the pool is sized for) and on one thread per PHYSICAL core of the affinity mask
-    (BASELINE.md section 4).  `value` / `cores` are the better of the two; both are reported."""
+    (BASELINE.md section 4).  `value` / `cores` are the better of the two; both are reported.  Beside the
+    bounded sample of the 800x800x128 frame, the whole 100x100x64 frame (BASELINE config 1) on the better
+    thread count: `config1_100x100x64`."""
     logical = os.cpu_count() or 1
     runs = []
     for threads, budget in ((min(logical, 16), 12.0), (physical_cores(), 10.0)):
@@ -163,7 +184,8 @@ def cpu_baseline():
             "kind": "port", "cpu": cpu_model(), "host_cpus": logical, "physical_cores": physical_cores(),
             "cgroup_cpu_quota": cpu_quota(), "runs": runs,
             "sample": f"{best['rays']} rays (whole 1024-ray chunks of the middle rows) of the same 800x800x128 "
-                      f"frame, {best['seconds']} s, torch {torch.__version__} CPU ops, oracle/nerf_oracle.py"}
+                      f"frame, {best['seconds']} s, torch {torch.__version__} CPU ops, oracle/nerf_oracle.py",
+            "config1_100x100x64": cpu_baseline_small(best["cores"])}
 
 
 def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32"):

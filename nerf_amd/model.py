@@ -131,7 +131,6 @@ class NeRF(nn.Module):
         self._packed_key = None
         self._tables = {}
         self._dead_draw_offsets = {}
-        self._philox_calls = 0
 
     # ---- statics (reference: nerf/model.py:243-367, :438-469) --------------------------------
 
@@ -201,23 +200,24 @@ class NeRF(nn.Module):
         return self._t_scale_value
 
     def _next_philox_state(self):
-        """(seed, offset) of the next in-kernel draw: the offset counts this module's launches and
-        carries the data-parallel rank in its high bits, so neither successive steps nor the ranks
-        of a job share a Philox key (include/nerf_hip.h: key = seed ^ offset)."""
+        """(seed, offset) of this module's in-kernel draws.  ONE word carries the launch sequence: the
+        device-resident counter of ``_philox_device_counter``, which the kernel adds to this offset and a
+        one-thread launch advances behind every drawing launch — eager launches and HIP-graph replays alike, so
+        an eager step between two replays cannot land on a replay's key (a host-side count frozen into a captured
+        argument block could: eager launches would move host + device, replays only the device word).  The
+        host part is therefore only the data-parallel rank in the high bits: neither successive launches nor the
+        ranks of a job share a Philox key (include/nerf_hip.h: key = seed ^ (offset + *rng_counter))."""
         rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
-        state = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF,
-                 ((rank & 0xFFFFFF) << 40) | (self._philox_calls & 0xFFFFFFFFFF))
-        self._philox_calls += 1
-        return state
+        return (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, (rank & 0xFFFFFF) << 40)
 
     def _philox_device_counter(self, device):
-        """The device-resident half of the launch counter (include/nerf_hip.h: rng_counter): every launch that
-        draws in-kernel adds this word to its Philox offset and is followed by a one-thread launch that
-        increments it.  Eagerly that only doubles what ``_philox_calls`` already does; inside a HIP-graph
-        replay — which repeats its argument block, the host-side offset included — it is what gives every
-        replayed step new draws (``Trainer(graph=True, rng="philox")``)."""
+        """The launch counter of this module's in-kernel draws, a DEVICE word (include/nerf_hip.h: rng_counter):
+        every launch that draws in-kernel adds it to its Philox offset and is followed by a one-thread launch
+        that increments it.  Device-resident because a HIP-graph replay repeats its argument block: this is what
+        gives every replayed step new draws (``Trainer(graph=True, rng="philox")``), and being the ONLY counter it
+        keeps eager and replayed launches on one sequence."""
         cur = getattr(self, "_philox_counter", None)
         if cur is None or cur.device != device:
             self._philox_counter = cur = torch.zeros(1, dtype=torch.int64, device=device)
@@ -395,7 +395,7 @@ class NeRF(nn.Module):
                 ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
                 want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None, rng_counter=None,
                 train_workspace=None, want_weights=False, cov=None, out_t=None):
-        """``rng_state`` None with ``rng_mode``: the module's own launch sequence (host counter + device counter,
+        """``rng_state`` None with ``rng_mode``: the module's own launch sequence (rank bits + the device counter,
         advanced behind the launch); an explicit state is used as it is (reproducible draws), plus
         ``rng_counter`` if the caller passes one (the training forward: its own sequence state, kept for the
         backward's argument block)."""

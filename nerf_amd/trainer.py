@@ -222,7 +222,12 @@ class Trainer:
         # Only this rank's FULL-batch share is warmed up, captured and replayed: a short batch (the
         # tail of an epoch, an uneven shard) runs eagerly and consumes no warm-up step, so the capture
         # can never freeze a tail size and then refuse every full batch for the rest of the run.
-        if n != self._full_share:
+        # The GLOBAL batch must be full as well: with the collective inside the graph the all-reduce weight is
+        # baked in as share / batch_size; a short global batch can still hand SOME ranks their full share, and
+        # those would replay with that weight while the others go eager with n / global_n — weights that no
+        # longer sum to 1.  `global_n` is the same number on every rank, so all ranks take the same path.
+        global_n = int(batch.get("global_n", n if not self.distributed else n * self.world))
+        if n != self._full_share or (self.distributed and global_n != self.batch_size):
             self._stale_grads = True                      # the eager step re-points p.grad
             return None
         if self._graph is None and self._eager_steps < 5:

@@ -119,6 +119,42 @@ def test_graph_replayed_training_fits_like_the_eager_loop(train_precision):
     assert run._graph_rays == 500 and last == last and last < 1.0
 
 
+@pytest.mark.gpu
+def test_philox_draws_stay_distinct_when_eager_steps_interleave_with_replays():
+    """Trainer(graph=True, rng="philox") with an epoch tail: replays and eager tail steps alternate.  The Philox key
+    of a launch is seed ^ (host offset + device counter); the host offset is constant (rank bits) and the device
+    counter is the ONE launch sequence, advanced by exactly one behind every drawing launch of either kind — so the
+    effective offsets of all steps are pairwise distinct (a host-side count beside it would let an eager step after
+    the capture land on the key of the next replay).  Checked on the offsets AND on the fenceposts drawn."""
+    from nerf_amd import trainer as T
+    dev = torch.device("cuda:0")
+    images, poses, focal = T.synthetic_scene(num_views=5, size=12, num_samples=16, device=dev)     # 576 training rays
+    run = T.Trainer(images, poses, focal, batch_size=100, learning_rate=5e-4, num_samples_per_ray=16,
+                    density_noise_std=0.5, log_interval=10 ** 9, seed=2, graph=True, rng="philox")
+    model, offsets, kinds = run.model, [], []
+    gen = torch.Generator().manual_seed(9)
+    sizes = [100] * 7 + [76, 100, 100, 76, 100, 76, 76, 100]            # full batches replay (from the 6th), tails are eager
+    for n in sizes:
+        idx = torch.randint(0, len(run.dataset), (n,), generator=gen)
+        seed, host = model._next_philox_state()
+        before = int(model._philox_device_counter(dev).item())
+        replays_before = run._graph is not None
+        run.iteration += 1
+        run.train_step(run.dataset.gather(idx.to(dev)))
+        torch.cuda.synchronize()
+        assert int(model._philox_counter.item()) == before + 1          # ONE advance per step, eager or replayed
+        offsets.append(host + before)
+        kinds.append("replay" if (replays_before and n == 100) else "eager")
+    assert len(set(offsets)) == len(offsets) and offsets == sorted(offsets)
+    assert kinds.count("replay") >= 4 and "eager" in kinds[8:]         # eager steps did run between replays
+    # the draws themselves: fenceposts of the same rays under each step's effective offset differ pairwise
+    o, d = torch.randn(8, 3, device=dev), torch.randn(8, 3, device=dev)
+    drawn = [model.fenceposts_used(o, d, 16, randomly_sample=True, rng_state=(seed, off)) for off in offsets]
+    for i in range(len(drawn)):
+        for j in range(i + 1, len(drawn)):
+            assert not torch.equal(drawn[i], drawn[j])
+
+
 def test_load_scene_reads_the_tiny_nerf_layout(tmp_path):
     """tiny_nerf_data.npz (examples/, not shipped: .MISSING_LARGE_BLOBS) holds images [V,H,W,3],
     poses [V,4,4] and a scalar focal; the loader must take a file of that layout (any float dtype)."""

@@ -71,16 +71,35 @@ def test_two_stage_render_vs_oracle(setup):
     assert (seg[:, 1].cpu() - seg_f)[ok].abs().max() <= 1e-4
     # end to end against the oracle's own pipeline: the coarse weights differ by rounding (1e-7), and fine posts
     # inside near-empty intervals are ill-conditioned in them, which moves a few rays' quadrature slightly
-    e2e = (img.cpu() - ref_img)[ok].abs().amax((-1, -2))
+    e2e_all = (img.cpu() - ref_img).abs().amax((-1, -2))
+    e2e = e2e_all[ok]
     assert (e2e <= 1e-4).float().mean() >= 0.98 and e2e.max() <= 2e-2
+    # ... and that is ALL the loose tail is allowed to be.  (i) A fine post t = t0 + (u - c0) / (c1 - c0) * dt moves
+    # by (CDF rounding) x dt / (mass of its interval): rays whose 128 fine posts all land in coarse intervals of PDF
+    # mass >= 1e-3 are well conditioned (351 of these 400 rays; with weights perturbed by 3e-7, three times the
+    # measured kernel-vs-oracle difference, the ORACLE moves those rays by <= 6e-5 and the others by up to 4e-3) and
+    # are held to 1e-4 without exception.
+    pdf = (w_ref + 1e-5) / (w_ref + 1e-5).sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros(400, 1), torch.cumsum(pdf, -1)], -1)
+    u_mid = ((torch.arange(128.0) + 0.5) / 128).expand(400, 128)
+    hit = (torch.searchsorted(cdf.contiguous(), u_mid.contiguous(), right=True) - 1).clamp(0, 62)
+    well = torch.gather(pdf, -1, hit).min(-1).values >= 1e-3
+    assert (well & ok).sum() >= 300
+    assert e2e_all[well & ok].max() <= 1e-4
+    # (ii) for EVERY ray the deviation is what the oracle itself shows between its posts and the kernel's posts
+    # (ref_f is the oracle on the kernel's union): nothing is left over for the renderer beyond the per-stage 1e-5.
+    explained = (ref_f - ref_img[:, 1]).abs().amax(-1)
+    assert ((img[:, 1].cpu() - ref_img[:, 1]).abs().amax(-1) <= explained + 1e-5)[ok].all()
     # the fine stage is a genuine refinement: close to the coarse render, not identical to it
     delta = (img[:, 1] - img[:, 0]).abs().max()
     assert 1e-6 < delta < 0.2
     full, _ = model.render_image_hierarchical(cam_o.to(dev), O.look_at_pose([0.0, -3.0, 2.6]).to(dev),
                                               20, 20, 22.4, 64, 128)
     # rays built by torch on the GPU here, on the CPU above: equal to rounding, not bitwise
-    diff = (full.reshape(-1, 3) - img[:, 1])[ok.to(dev)].abs().amax(-1)
+    diff_all = (full.reshape(-1, 3) - img[:, 1]).abs().amax(-1).cpu()
+    diff = diff_all[ok]
     assert (diff <= 1e-4).float().mean() >= 0.98 and diff.max() <= 2e-2
+    assert diff_all[well & ok].max() <= 1e-4                    # the well-conditioned rays, as above
 
 
 def test_two_stage_training_step(setup):
