@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 6
+#define NERF_HIP_ABI_VERSION 7
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -121,7 +121,10 @@ typedef struct NerfHipRenderArgs {
     float* out_raw;             /* [n_rays,S-1,num_outputs] density | color | segmentation logits */
     float* out_weights;         /* [n_rays,S-1] compositing weights (model.py:438-469)     */
     /* training: non-NULL makes the forward also save what the backward needs (activations,
-     * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats      */
+     * LayerNorm statistics, compositing state); nerf_hip_train_workspace_bytes() floats.
+     * A training forward may also be asked for out_raw / out_mean / out_cov (a DIFFERENTIABLE
+     * NeRF.forward, model.py:553-594: its backward is nerf_hip_render_backward with d_raw);
+     * out_t is not produced by it. */
     float* train_workspace;
     /* arithmetic of the MLP.  On a training forward it also selects the arithmetic of the data
      * gradient (dX = W^T dY) and of the weight gradient (dW = dY^T X; f16 pairs with one power-of-two
@@ -154,13 +157,18 @@ size_t nerf_hip_grad_elements(int32_t hidden, int32_t enc_inputs, int32_t num_ou
 /* Backward of nerf_hip_render_forward w.r.t. the parameters (replaces PyTorch autograd through
  * NeRF.render_rays, driven by loss.backward() at train_conditional_nerf.py:133).  `fwd` must be
  * the argument block of the training forward call (same rays, sampling inputs, draws, packed
- * image and train_workspace, which that call filled); rays are not differentiated. */
+ * image and train_workspace, which that call filled); rays are not differentiated.
+ * Two forms: the loss reached the COMPOSITED outputs (d_rgb, optionally d_seg; d_raw NULL: NeRF.render_rays,
+ * model.py:596-668), or it reached the PER-SAMPLE network outputs of NeRF.forward (model.py:553-594: density |
+ * color | segmentation logits; d_raw non-NULL, d_rgb / d_seg ignored) — then the compositing backward is skipped
+ * and d_raw enters the data- and weight-gradient kernels directly. */
 typedef struct NerfHipBackwardArgs {
     NerfHipRenderArgs fwd;
     const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
     const float* d_seg;         /* [n_rays,num_outputs-4] dL/d seg or NULL (RGB-only loss) */
     float* grad;                /* [nerf_hip_grad_elements(hidden, enc_inputs, num_outputs)] written (not accumulated) */
     float* scratch;             /* nerf_hip_backward_scratch_bytes() bytes                 */
+    const float* d_raw;         /* [n_rays,S-1,num_outputs] dL/d out_raw, or NULL          */
 } NerfHipBackwardArgs;
 
 size_t nerf_hip_backward_scratch_bytes(int64_t n_rays, int32_t num_samples);

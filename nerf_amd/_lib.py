@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -43,7 +43,7 @@ class RenderArgs(ctypes.Structure):
 class BackwardArgs(ctypes.Structure):
     """Mirror of NerfHipBackwardArgs (include/nerf_hip.h)."""
     _fields_ = [("fwd", RenderArgs), ("d_rgb", _f32p), ("d_seg", _f32p), ("grad", _f32p),
-                ("scratch", _f32p)]
+                ("scratch", _f32p), ("d_raw", _f32p)]
 
 
 class GatherArgs(ctypes.Structure):

@@ -84,3 +84,62 @@ class RenderRaysFunction(torch.autograd.Function):
             off += n
         model.last_flat_grad = grad
         return (None,) * 10 + tuple(grads)
+
+
+class FieldFunction(torch.autograd.Function):
+    """mean [N,S-1,3], raw [N,S-1,num_outputs] = f(parameters): the per-sample outputs of ``NeRF.forward``
+    (nerf/model.py:553-594) with a backward — the reference's ``forward`` is an ordinary ``nn.Module.forward``, a loss
+    on its density / colour / segmentation back-propagates into the parameters.  Forward = the training forward (the
+    network outputs are already in its workspace; one small launch copies them out), backward =
+    nerf_hip_render_backward in its ``d_raw`` form: the compositing backward is skipped, dL/d(raw) enters the
+    data-gradient and weight-gradient kernels directly.  ``mean`` does not depend on the parameters."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, samples, *params):
+        lib = _lib.lib()
+        n_rays, num_samples, device = samples.shape[0], samples.shape[-1], rays_o.device
+        ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
+        workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
+        rgb, seg, mean, raw, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
+                                               t_values=samples, per_sample=True, train_workspace=workspace)
+        ctx.model = model
+        ctx.call = (rays_o, rays_d, samples, rgb, seg)
+        ctx.workspace = workspace
+        ctx.precision = _lib.PRECISIONS[model.train_precision]
+        ctx.packed = model._last_packed
+        ctx.shapes = [p.shape for p in params]
+        ctx.mark_non_differentiable(mean)
+        return mean, raw
+
+    @staticmethod
+    def backward(ctx, _d_mean, d_raw):
+        lib = _lib.lib()
+        model = ctx.model
+        rays_o, rays_d, samples, rgb, seg = ctx.call
+        n_rays, num_samples, device = samples.shape[0], samples.shape[-1], rays_o.device
+        if d_raw is None:
+            return (None,) * (4 + len(ctx.shapes))
+        d_raw = d_raw.contiguous()
+        args = _lib.BackwardArgs()
+        model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, t_values=samples,
+                         packed=ctx.packed, rgb=rgb, seg=seg if model.segmentation_outputs > 0 else None,
+                         train_workspace=ctx.workspace, precision=ctx.precision)
+        grad = torch.empty(lib.nerf_hip_grad_elements(model.hidden_size, model.enc_inputs, model.num_outputs),
+                           dtype=torch.float32, device=device)
+        scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)
+        args.d_raw = _lib.ptr(d_raw)
+        args.grad, args.scratch = _lib.ptr(grad), _lib.ptr(scratch)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.nerf_hip_render_backward(ctypes.byref(args), ctypes.c_void_p(stream)),
+                       "nerf_hip_render_backward")
+        ctx.workspace = None
+        grads, off = [], 0
+        for shape in ctx.shapes:
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(grad[off:off + n].view(shape))
+            off += n
+        model.last_flat_grad = grad
+        return (None,) * 4 + tuple(grads)

@@ -41,6 +41,7 @@ struct BwdArgs {
     NerfHipRenderArgs a;
     const float* d_rgb;
     const float* d_seg;
+    const float* d_raw;         // [n_rays][P][num_outputs] or null: the loss reached NeRF.forward's outputs directly
     int32_t intervals, chunks;
     int64_t groups;
     TrainLayout L;
@@ -63,6 +64,27 @@ __global__ __launch_bounds__(256) void nerf_composite_bwd_kernel(const BwdArgs b
     cb.intervals = ba.intervals, cb.chunks = ba.chunks;
     cb.mp = ba.L.mp, cb.out = ba.L.out, cb.comp = ba.L.comp, cb.dy5_rows = ba.a.train_workspace + ba.L.dy5;
     composite_bwd_body(ba.a, cb);
+}
+
+// dL/d(out) rows from dL/d(out_raw) (the backward of a differentiable NeRF.forward, nerf/model.py:553-594, takes
+// the compositing backward's place): thread = (padded sample, four columns); padding rows / columns get zeros.
+__global__ __launch_bounds__(256) void nerf_field_scatter_kernel(const BwdArgs ba) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ba.L.mp * (kOutPad / 4)) return;
+    const int q = (int)(e & (kOutPad / 4 - 1));
+    const int64_t sp = e >> 4;
+    const int64_t tile = sp >> 4;
+    const int64_t slot = tile / ba.chunks;
+    const int s = (int)(tile - slot * ba.chunks) * 16 + (int)(sp & 15);
+    const int n_out = ba.a.num_outputs;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (slot < ba.a.n_rays && s < ba.intervals) {
+        const float* src = ba.d_raw + (slot * ba.intervals + s) * n_out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * q + k < n_out) v[k] = src[4 * q + k];
+    }
+    *(f32x4*)(ba.a.train_workspace + ba.L.dy5 + sp * kOutPad + 4 * q) = v;
 }
 
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba) {
@@ -420,8 +442,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
         return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)grad_elements(shape_of(a)) * sizeof(float),
                                                      (hipStream_t)stream), "render_backward memset");
-    if (args->scratch == nullptr || args->d_rgb == nullptr)
-        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: scratch / d_rgb is null");
+    if (args->scratch == nullptr || (args->d_rgb == nullptr && args->d_raw == nullptr))
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: scratch is null, or neither d_rgb nor d_raw is given");
     if (a.train_workspace == nullptr || a.packed == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: forward was not a training forward");
     if (args->d_seg != nullptr && a.seg == nullptr)
@@ -434,6 +456,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.a = a;
     ba.d_rgb = args->d_rgb;
     ba.d_seg = args->d_seg;
+    ba.d_raw = args->d_raw;
     ba.intervals = a.num_samples - 1;
     ba.chunks = (ba.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     ba.L = make_train_layout(a.n_rays, ba.chunks);
@@ -474,8 +497,11 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;
     ba.data_grid = (int)grid;
 
-    hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
-                       dim3(256), 0, st, ba);
+    if (ba.d_raw != nullptr)
+        hipLaunchKernelGGL(nerf_field_scatter_kernel, dim3((unsigned)((ba.L.mp * (kOutPad / 4) + 255) / 256)), dim3(256), 0, st, ba);
+    else
+        hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
+                           dim3(256), 0, st, ba);
     if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
     else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     const int wgrad_jobs = 6;

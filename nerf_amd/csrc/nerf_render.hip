@@ -444,6 +444,34 @@ __global__ __launch_bounds__(256) void nerf_composite_fwd_kernel(const KernelArg
     composite_fwd_body(ka.a, ka.intervals, ka.chunks, ka.save.out, ka.save.comp);
 }
 
+// Per-sample outputs of a TRAINING forward (a differentiable NeRF.forward, nerf/model.py:553-594): the network
+// outputs are already in the workspace (padded tiles), this copies the real ones out in the reference's
+// [n_rays, S-1, num_outputs] layout; the thread of column 0 also recomputes the sample's Gaussian (the same
+// operations as the render kernel's front end: same bits) for out_mean / out_cov.
+__global__ __launch_bounds__(256) void nerf_field_outputs_kernel(const KernelArgs ka) {
+    const NerfHipRenderArgs& a = ka.a;
+    const int P = ka.intervals, n_out = a.num_outputs;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_rays * P * n_out) return;
+    const int n = (int)(e % n_out);
+    const int64_t smp = e / n_out;
+    const int64_t local = smp / P;
+    const int s = (int)(smp - local * P);
+    const int64_t tile = local * ka.chunks + (s >> 4);
+    const int j = s & 15;
+    if (a.out_raw != nullptr)
+        a.out_raw[e] = a.train_workspace[ka.save.out + tile * 1024 + (n >> 4) * 256 + (((n & 15) >> 2) * 16 + j) * 4 + (n & 3)];
+    if (n == 0 && (a.out_mean != nullptr || a.out_cov != nullptr)) {
+        const Ray ray = load_ray(a, local);
+        const Gaussian gm = frustum(ray, fencepost(a, local, s), fencepost(a, local, s + 1), a.base_radius_sq);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (a.out_mean != nullptr) a.out_mean[smp * 3 + k] = gm.mean[k];
+            if (a.out_cov != nullptr) a.out_cov[smp * 3 + k] = gm.cov[k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // parameter re-layout (state_dict order -> packed image)
 // ---------------------------------------------------------------------------------------------
@@ -724,8 +752,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     const bool train = a.train_workspace != nullptr;
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
-    if (train && (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr || a.out_t != nullptr))
-        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_raw / out_mean / out_cov / out_t are not produced by the training forward");
+    if (train && a.out_t != nullptr)
+        return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: out_t is not produced by the training forward");
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave
     ka.groups = train ? ka.save.mp / 16 / kWavesPerWg : (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
 
@@ -760,6 +788,10 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (train) {
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
+        if (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr) {
+            const int64_t elems = a.n_rays * ka.intervals * a.num_outputs;
+            hipLaunchKernelGGL(nerf_field_outputs_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, ka);
+        }
     }
     rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
     nerf_common::Timing::after(st);

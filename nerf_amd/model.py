@@ -480,14 +480,19 @@ class NeRF(nn.Module):
     def forward(self, rays_o, rays_d, samples, states_x=None, states_d=None):
         """Field values on the intervals of ``samples`` [N, S]: returns (mean [N,S-1,3],
         density [N,S-1,1], color [N,S-1,3], segmentation [N,S-1,50])  (nerf/model.py:553-594).
-        ``states_*`` are accepted and ignored, as in the reference."""
+        ``states_*`` are accepted and ignored, as in the reference.  Like the reference's it is differentiable
+        w.r.t. the parameters when gradients are enabled (a loss on density / color / segmentation trains the
+        network: nerf_amd/backward.py FieldFunction); under ``torch.no_grad()`` it is the plain inference launch."""
         _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
         _require_device(samples, "samples")
         n_rays, num_samples = samples.shape[0], samples.shape[-1]
-        _, _, mean, raw, _ = self._launch(
-            n_rays, num_samples, rays_o.device, rays_o=rays_o.detach().contiguous(),
-            rays_d=rays_d.detach().contiguous(), t_values=samples.detach().contiguous(),
-            want_seg=False, per_sample=True)
+        o, d, t = rays_o.detach().contiguous(), rays_d.detach().contiguous(), samples.detach().contiguous()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .backward import FieldFunction
+            mean, raw = FieldFunction.apply(self, o, d, t, *self._param_list())
+        else:
+            _, _, mean, raw, _ = self._launch(n_rays, num_samples, rays_o.device, rays_o=o, rays_d=d, t_values=t,
+                                              want_seg=False, per_sample=True)
         density, color, seg = raw.split([1, self.color_outputs, self.segmentation_outputs], dim=2)
         return mean, density, color, seg
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(handle):
     for name in names:
         assert hasattr(handle, name), name
     assert set(_lib.EXPORTS) == set(names)
-    assert handle.nerf_hip_version() == _lib.ABI_VERSION == 6
+    assert handle.nerf_hip_version() == _lib.ABI_VERSION == 7
     # packed image = {74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB} x {fp32, f16 pairs}
     assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4 + 68 * 16384) + 16      # + four bound constants
     ge = handle.nerf_hip_grad_elements

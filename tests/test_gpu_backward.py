@@ -131,6 +131,61 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
         assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
 
 
+@pytest.mark.parametrize("n_rays,num_samples,which", [(7, 9, "all"), (64, 33, "density+color"), (130, 64, "all"),
+                                                     (33, 20, "seg")])
+def test_forward_is_differentiable_like_the_reference(dev, n_rays, num_samples, which):
+    """NeRF.forward (nerf/model.py:553-594) is an ordinary nn.Module.forward in the reference: a loss on its per-sample
+    density / color / segmentation back-propagates into the 22 parameters.  Here that is the training forward + the
+    `d_raw` form of nerf_hip_render_backward (no compositing backward).  Values and gradients against the oracle's
+    field() and its autograd, same bound as the render_rays gradients; and the no-grad launch returns the same values."""
+    torch.manual_seed(300 + n_rays)
+    params = golden_params(2.0)
+    for k in list(params):
+        if k.startswith("prediction") and params[k].dim() == 1:
+            params[k] = params[k] + 0.2 * torch.randn_like(params[k])
+    o, d = torch.randn(n_rays, 3), torch.randn(n_rays, 3)
+    t = torch.sort(torch.rand(n_rays, num_samples) * 40 + 0.1, dim=-1).values
+    P = num_samples - 1
+    w_d = torch.randn(n_rays, P, 1) * ("density" in which or which == "all")
+    w_c = torch.randn(n_rays, P, 3) * ("color" in which or which == "all")
+    w_s = torch.randn(n_rays, P, 50) * 0.1 * (which in ("all", "seg"))
+
+    def loss_of(p, dtype):
+        _, _, _, dens, col, seg = O.field(p, CFG, o.to(dtype), d.to(dtype), t.to(dtype))
+        return (dens * w_d.to(dtype)).sum() + (col * w_c.to(dtype)).sum() + (seg * w_s.to(dtype)).sum(), (dens, col, seg)
+
+    ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    loss_r, (dens_r, col_r, seg_r) = loss_of(ref, torch.float32)
+    loss_r.backward()
+    exact = fp64_gradients(params, lambda p: loss_of(p, torch.float64)[0])
+
+    model = make_model(dev, params)
+    mean, dens, col, seg = model(o.to(dev), d.to(dev), t.to(dev))
+    assert dens.requires_grad and col.requires_grad and seg.requires_grad and not mean.requires_grad
+    assert dens.shape == (n_rays, P, 1) and col.shape == (n_rays, P, 3) and seg.shape == (n_rays, P, 50)
+    for got, want in ((dens, dens_r), (col, col_r), (seg, seg_r)):
+        assert (got.detach().cpu() - want.detach()).abs().max() <= 2e-5 * max(1.0, float(want.detach().abs().max()))
+    means_r = O.field(params, CFG, o, d, t)[0]
+    assert (mean.cpu() - means_r).abs().max() <= 1e-5 * max(1.0, float(means_r.abs().max()))
+    loss = (dens * w_d.to(dev)).sum() + (col * w_c.to(dev)).sum() + (seg * w_s.to(dev)).sum()
+    loss.backward()
+    noise_floor = max(rel_err(ref[k].grad, exact[k]) for k, _ in model.named_parameters())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == ref[k].grad.shape, k
+        e = rel_err(p.grad.cpu(), ref[k].grad)
+        worst = max(worst, e)
+        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+    print(f"forward() gradients: worst relative error {worst:.2e} (fp32-vs-fp64 floor of the oracle {noise_floor:.2e})")
+    if which == "density+color":                        # the 50 segmentation rows saw no loss
+        assert torch.count_nonzero(model.prediction_heads[15].weight.grad[4:]) == 0
+    with torch.no_grad():                                # inference launch: same field, no workspace
+        mean0, dens0, col0, seg0 = model(o.to(dev), d.to(dev), t.to(dev))
+    assert not dens0.requires_grad
+    for a, b in ((mean0, mean), (dens0, dens), (col0, col), (seg0, seg)):
+        assert (a - b.detach()).abs().max() <= 2e-5 * max(1.0, float(b.detach().abs().max()))
+
+
 def test_backward_is_deterministic_and_accumulates(dev):
     torch.manual_seed(1)
     model = make_model(dev, golden_params(3.0))
