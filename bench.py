@@ -488,15 +488,15 @@ def baseline_configs(dev):
             _lib.timing(False)
         return dt, kernel_ms, launches // steps
 
-    def entry(workload, dt, nominal, evaluated, steps, kernel_ms, launches):
-        tf = evaluated * FLOP_PER_SAMPLE / dt / 1e12
+    def entry(workload, dt, nominal, evaluated, steps, kernel_ms, launches, flop_per_sample=FLOP_PER_SAMPLE):
+        tf = evaluated * flop_per_sample / dt / 1e12
         return {"workload": workload, "steps": steps, "ms_per_step": dt * 1e3, "ray_samples_per_s": nominal / dt,
                 "evaluated_samples": evaluated, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TFLOPS_FP32_MFMA,
                 "render_launches_per_step": launches, "avg_render_kernel_ms": kernel_ms}
 
-    def model_for(focal, scale=1.0):
+    def model_for(focal, scale=1.0, **shape):
         torch.manual_seed(0)
-        m = NeRF(focal_length=focal)
+        m = NeRF(focal_length=focal, **shape)
         if scale != 1.0:
             with torch.no_grad():
                 for slot in (0, 3, 6, 9, 12, 15):
@@ -523,6 +523,18 @@ def baseline_configs(dev):
     out["headline_weights_x3"] = entry("the headline 800x800x128 frame with every Linear weight x3 (early "
                                        "saturation: the kernel has no early-out, cost must not change)",
                                        dt, IMAGE * IMAGE * SAMPLES, IMAGE * IMAGE * (SAMPLES - 1), 3, k, n)
+    # narrow networks at their own cost (nerf/model.py:471-475: hidden_size / encoding_size are constructor keywords):
+    # the headline frame through the kernels instantiated for 8 and 4 register tiles per sample; algorithmic FLOP =
+    # 2 (3 enc H + 4 H^2 + 54 H) per evaluated sample, against the same fp32 MFMA peak
+    for name, hidden, enc in (("narrow_hidden128", 128, 32), ("narrow_hidden64_enc16", 64, 16)):
+        m = model_for(FOCAL, hidden_size=hidden, encoding_size=enc)
+        flop = 2 * (3 * enc * hidden + 4 * hidden * hidden + 54 * hidden)
+        dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=5)
+        out[name] = entry(f"the headline 800x800x128 frame, hidden_size={hidden}, encoding_size={enc}: the fp32 kernel "
+                          f"instantiated at {16 if hidden > 128 else (8 if hidden > 64 else 4)} register tiles per sample "
+                          f"(not zero-padded to 256); {flop} FLOP per sample", dt, IMAGE * IMAGE * SAMPLES,
+                          IMAGE * IMAGE * (SAMPLES - 1), 5, k, n, flop_per_sample=flop)
+        out[name]["flop_per_sample"] = flop
     return out
 
 

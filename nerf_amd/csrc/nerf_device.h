@@ -112,18 +112,17 @@ __host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g) {      // t
 
 // The network's shape from an argument block (0 = the defaults 256 / 96), and what the LayerNorms need of it:
 // they divide their sums by hidden_size, not by the 256 features the kernels carry — the padded ones are exactly
-// zero before normalisation (nerf_layout.h: Shape) — and the two-pass variance takes their (0 - mean)^2 terms out.
+// zero before normalisation (nerf_layout.h: Shape) — and the second pass of the variance is written so that they add exactly nothing (nerf_fused.h).
 __host__ __device__ inline Shape shape_of(const NerfHipRenderArgs& a) {
     return Shape{a.hidden > 0 ? a.hidden : kHidden, a.enc_inputs > 0 ? a.enc_inputs : kEncIn, a.num_outputs};
 }
 struct NormDivisor {
-    float inv_n;                // 1 / hidden_size
-    float padded;               // 256 - hidden_size
+    float inv_n;                // 1 / hidden_size (features beyond it are padding: exactly 0 before normalisation)
 };
 __host__ __device__ inline NormDivisor norm_divisor(int hidden) {
-    return NormDivisor{1.0f / (float)hidden, (float)(kHidden - hidden)};
+    return NormDivisor{1.0f / (float)hidden};
 }
-constexpr NormDivisor kFullWidth = {1.0f / 256.0f, 0.f};
+constexpr NormDivisor kFullWidth = {1.0f / 256.0f};
 
 // ---------------------------------------------------------------------------------------------
 // weight stream: global -> LDS by LDS-DMA, two stages ahead of the MFMAs

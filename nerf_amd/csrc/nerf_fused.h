@@ -123,10 +123,10 @@ __device__ __forceinline__ void interleave_7() {
 
 // Moments -> the deferred normalisation of `raw` (the layer's finished accumulators).
 // var = E[x^2] - mean^2 cancels when |mean| >> std, so whenever the mean carries more than 3/4 of
-// the second moment in ANY sample of the wave, the exact two-pass variance is taken instead
+// the second moment in ANY sample of the wave, a mean-shifted second pass is taken instead
 // (wave-uniform branch; pre-LayerNorm activations of this network have |mean| well below std, so
 // it is cold).  1/sqrt: hardware estimate (1 ulp) + one Newton step.
-template <bool kTrain, class Mom, int kOrder = kOrderNormRelu>
+template <bool kTrain, class Mom, int kOrder = kOrderNormRelu, int NT = 16>
 __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 (&raw)[16], const f32x4* gam,
                                                       const f32x4* bet, int g, float* save_row,
                                                       float* save_rstd, float eps = 1e-5f,
@@ -136,17 +136,21 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
     const float ex2 = group_sum(m.sum_sq()) * nd.inv_n;
     float var = ex2 - mean * mean;
     if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
+        // second pass, mean-shifted:  sum (x - mean) x  =  sum (x - mean)^2  (because sum (x - mean) = 0): its rounding
+        // error is eps (1 + |mean| / std) of the variance against eps (1 + mean^2 / var) of the one-pass form above.
+        // Written with x as the second factor so that a narrower network's padded features — exactly 0 here — add
+        // exactly nothing: no mask per element (+790 instructions per kernel when tried), and no "sum all 256, subtract
+        // padded * mean^2" (which brings the cancellation back, amplified by padded / hidden: ADVICE r4).
         float v = 0.f;
 #pragma unroll
-        for (int T = 0; T < 16; ++T) {
+        for (int T = 0; T < NT; ++T) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float d = (kOrder == kOrderReluNorm ? __builtin_fmaxf(raw[T][r], 0.f) : raw[T][r]) - mean;
-                v = __builtin_fmaf(d, d, v);
+                const float x = kOrder == kOrderReluNorm ? __builtin_fmaxf(raw[T][r], 0.f) : raw[T][r];
+                v = __builtin_fmaf(x - mean, x, v);
             }
         }
-        // (a narrower network's padded features are exactly 0 here: their (0 - mean)^2 terms do not belong)
-        var = (group_sum(v) - nd.padded * mean * mean) * nd.inv_n;
+        var = group_sum(v) * nd.inv_n;
     }
     const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
@@ -163,12 +167,12 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
 }
 
 // gamma / beta of a layer at their place in the main network's padded LDS image (nerf_device.h)
-template <bool kTrain, class Mom>
+template <bool kTrain, class Mom, int NT = 16>
 __device__ __forceinline__ LazyNorm finish_moments(const Mom& m, const f32x4 (&raw)[16],
                                                    const float* small_l, int g, float* save_row,
                                                    float* save_rstd, const NormDivisor nd, float eps = 1e-5f,
                                                    float save_scale = 1.0f) {
-    return finish_moments_at<kTrain, Mom>(m, raw, (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride),
+    return finish_moments_at<kTrain, Mom, kOrderNormRelu, NT>(m, raw, (const f32x4*)(small_l + kSmallArrayLds + g * kSmallGStride),
                                           (const f32x4*)(small_l + 2 * kSmallArrayLds + g * kSmallGStride), g,
                                           save_row, save_rstd, eps, save_scale, nullptr, nd);
 }

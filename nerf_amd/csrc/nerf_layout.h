@@ -79,7 +79,36 @@ constexpr int kImageFloats = kBwdHBlobOffset + kBwdBlobFloats;          // the s
 //       bounds a sample's |dL/dy_0| from two scalars it holds (nerf_backward.hip: nerf_bwd_data_h_kernel) — the
 //       layer-0 weight-gradient job's f16 scale; [1..3] unused
 constexpr int kBoundsOffset = kImageFloats;
-constexpr int kPackedFloats = kImageFloats + 4;
+constexpr int kWideFloats = kImageFloats + 4;
+
+// NARROW networks at their own cost (hidden_size <= 128 or <= 64): a second fp32 image of the inference path,
+// behind the six full-width ones, for kernels instantiated at NT = 8 or 4 register tiles per sample instead of 16.
+// Same 16 KiB stages of 16 quads, same quad format; what changes is how many k-groups a stage holds.  With NT out
+// tiles per k-group a layer's quads are numbered qq = k-group * NT + out tile and cut into stages of 16:
+//   layer 0:   KG0 k-groups (6, the 96 padded encoding inputs; 8 for NT = 4 so that the layer ends on a stage
+//              boundary — k-groups 6, 7 are zero) x NT out tiles
+//   layers 1-4: NT k-groups x NT out tiles  = NT^2 / 16 stages each
+//   layer 5:   NT / 4 stages of 4 k-groups x 4 out tiles (quad = (t - 4 s) * 4 + T, as in the full-width image)
+// The MFMA loop is the full-width one (a stage = 8 groups of 2 quads = 64 MFMAs); only the (stage, group) ->
+// (k-group, out-tile pair) map differs.  bias / gamma / beta come from the full-width small image.
+template <int NT>
+struct Narrow {
+    static_assert(NT == 16 || NT == 8 || NT == 4, "register tiles per sample");
+    static constexpr int kTiles = NT;
+    static constexpr int kKGroups0 = NT == 4 ? 8 : 6;                       // k-groups of layer 0 (zero-padded)
+    static constexpr int kStages0 = kKGroups0 * NT / 16;
+    static constexpr int kStagesHid = NT * NT / 16;
+    static constexpr int kStages5 = NT / 4;
+    static constexpr int kStages = kStages0 + 4 * kStagesHid + kStages5;     // 74 / 21 / 7
+    static constexpr int kFloats = kStages * kStageFloats;
+};
+static_assert(Narrow<16>::kStages == kNumStages, "NT = 16 is the full-width image");
+constexpr int kNarrow8Offset = kWideFloats;                                  // 16-byte aligned (kWideFloats % 4 == 0)
+constexpr int kNarrow4Offset = kNarrow8Offset + Narrow<8>::kFloats;
+constexpr int kPackedFloats = kNarrow4Offset + Narrow<4>::kFloats;
+static_assert(kWideFloats % 4 == 0, "narrow images start 16-byte aligned");
+// register tiles a network of `hidden` features needs, rounded up to an instantiated width
+__host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16); }
 
 // Network shape at run time (include/nerf_hip.h: hidden / enc_inputs / num_outputs of the argument blocks): the kernels always compute the compiled-in
 // 256 / 96 / 64 widths; a narrower network (hidden_size H <= 256, encoding_size with S = enc / 2 <= 16 scales,
@@ -87,7 +116,7 @@ constexpr int kPackedFloats = kImageFloats + 4;
 //   * padded rows / columns of every weight matrix, padded biases, gamma and beta are zero in the packed images,
 //     so a padded feature carries 0 into every product and the padded scales of the encoding meet zero weights;
 //   * LayerNorm divides its sums by H, not 256 (the padded pre-activations are exactly 0 and add nothing to the
-//     sum or the sum of squares; the two-pass fallback subtracts their (0 - mean)^2 terms);
+//     sum or the sum of squares; the mean-shifted second pass of the variance, sum (x - mean) x, gets exactly 0 from them);
 //   * a padded feature's normalised value is not zero, but gamma = beta = 0 makes its activation, its ReLU gate
 //     and every gradient that reaches a REAL parameter through it exactly zero; what the backward computes for
 //     padded parameters is never copied into the flat gradient.

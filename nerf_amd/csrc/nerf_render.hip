@@ -158,6 +158,121 @@ __device__ __forceinline__ void layer_out(FwdPipe& pipe, f32x4 (&in)[16], f32x4 
     __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 
+// ---------------------------------------------------------------------------------------------
+// NARROW instantiations (nerf_layout.h: Narrow<NT>, NT = 8 or 4 register tiles per sample): the same software
+// pipeline — a stage = 8 groups of two quads = 64 MFMAs, next group's ds_read_b128 behind the first MFMA, stage
+// hand-over at the last group — with NT / 2 groups per k-group instead of 8: group p of the layer works on k-group
+// p / (NT / 2) and the out-tile pair 2 (p % (NT / 2)).  The lazy normalisation of the next k-group's tile and the
+// moments of finished tile pairs ride in the MFMA shadow exactly as in layer_fused (which is this function at
+// NT = 16; the full-width kernels keep their own copy so that their code does not move).
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void load_bias_n(const float* small_l, int g, f32x4 (&acc)[16]) {
+    const f32x4* b = (const f32x4*)(small_l + g * kSmallGStride);
+#pragma unroll
+    for (int T = 0; T < NT; ++T) acc[T] = b[T];
+}
+
+template <int NT, int KG, bool kNormIn, bool kTrain, class Pipe>
+__device__ __forceinline__ void layer_fused_n(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
+                                              const LazyNorm& norm, Moments& mom) {
+    constexpr int kPerK = NT / 2;                 // groups (tile pairs) per k-group
+    constexpr int kGroups = KG * kPerK;           // groups of the layer
+    static_assert(kGroups % 8 == 0, "a layer ends on a stage boundary");
+    if (kNormIn) normalize_tile<kTrain>(in[0], norm, 0);
+    mom.reset();
+    f32x4 a[2][2];
+    f32x4 ga, be;
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    const f32x4* st = pipe.open_stage();
+    a[0][0] = st[0];
+    a[0][1] = st[64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int p = 0; p < kGroups; ++p) {
+        const int k = p / kPerK, lp = p % kPerK, tp = p % 8;
+        const int T0 = 2 * lp, T1 = 2 * lp + 1;
+        const float b0 = in[k].x, b1 = in[k].y, b2 = in[k].z, b3 = in[k].w;
+        const int cur = p & 1, nxt = cur ^ 1;
+        const f32x4 a0 = a[cur][0], a1 = a[cur][1];
+        out[T0] = mfma4(a0.x, b0, out[T0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tp < 7) {
+            a[nxt][0] = st[(2 * tp + 2) * 64];
+            a[nxt][1] = st[(2 * tp + 3) * 64];
+            if (kNormIn && lp == 0 && k + 1 < KG) {          // a whole group ahead of their use
+                ga = norm.gam[k + 1];
+                be = norm.bet[k + 1];
+            }
+        } else if (p + 1 < kGroups) {
+            st = pipe.open_stage();
+            a[nxt][0] = st[0];
+            a[nxt][1] = st[64];
+            pipe.prefetch_next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        out[T1] = mfma4(a1.x, b0, out[T1]);
+        out[T0] = mfma4(a0.y, b1, out[T0]);
+        out[T1] = mfma4(a1.y, b1, out[T1]);
+        out[T0] = mfma4(a0.z, b2, out[T0]);
+        out[T1] = mfma4(a1.z, b2, out[T1]);
+        out[T0] = mfma4(a0.w, b3, out[T0]);
+        out[T1] = mfma4(a1.w, b3, out[T1]);
+        if (kNormIn && lp == 1 && k + 1 < KG) {
+            normalize_tile<kTrain>(in[k + 1], norm, k + 1, ga, be);
+            interleave_7<2>();
+        }
+        if (k == KG - 1 && lp >= 1) {             // tile pair finished one group ago
+            mom.add(out[2 * lp - 2]);
+            mom.add(out[2 * lp - 1]);
+            in[2 * lp - 2] = out[2 * lp - 2];
+            in[2 * lp - 1] = out[2 * lp - 1];
+            interleave_7<4>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mom.add(out[NT - 2]);
+    mom.add(out[NT - 1]);
+    in[NT - 2] = out[NT - 2];
+    in[NT - 1] = out[NT - 1];
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+}
+
+// Layer 5 of a narrow network (16 NT -> 64 padded): NT / 4 stages of 4 k-groups x 4 out tiles.
+template <int NT, bool kTrain, class Pipe>
+__device__ __forceinline__ void layer_out_n(Pipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4], const LazyNorm& norm) {
+    normalize_tile<kTrain>(in[0], norm, 0);
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+#pragma unroll
+    for (int s = 0; s < NT / 4; ++s) {
+        const f32x4* st = pipe.open_stage();
+        f32x4 q[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = st[i * 64];
+        pipe.prefetch_next();
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int t = 4 * s + tl;
+            if (tl + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[((tl + 1) & 1) * 4 + i] = st[(4 * (tl + 1) + i) * 64];
+            }
+            const f32x4 a0 = q[(tl & 1) * 4 + 0], a1 = q[(tl & 1) * 4 + 1], a2 = q[(tl & 1) * 4 + 2],
+                        a3 = q[(tl & 1) * 4 + 3];
+            const f32x4 b = in[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0] = mfma4(a0[r], b[r], acc[0]);
+                acc[1] = mfma4(a1[r], b[r], acc[1]);
+                acc[2] = mfma4(a2[r], b[r], acc[2]);
+                acc[3] = mfma4(a3[r], b[r], acc[3]);
+            }
+            if (t + 1 < NT) normalize_tile<kTrain>(in[t + 1], norm, t + 1);
+        }
+    }
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+}
+
 
 // Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
 // block m + 1 is built during the four units of block m.
@@ -231,9 +346,12 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
 // kPerSample: the instantiation that also writes the optional per-sample outputs (NeRF.forward's
 // tensors, compositing weights for the hierarchical resampler, debug outputs); the render-only
 // instantiations carry none of that code or its registers.
-template <bool kTrain, bool kHalf, bool kPerSample = false>
+template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
+    static_assert(NT == 16 || (!kTrain && !kHalf), "narrow instantiations: fp32 inference");
+    typedef Narrow<NT> N;
+    typedef WeightPipe<N::kStages> Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -248,13 +366,13 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     }
     const float* small = (const float*)(smem + kRingBytes);
 
-    FwdPipe pipe;
-    pipe.init(a.packed + (kHalf ? kHBlobOffset : 0), smem, wave, lane);
+    Pipe pipe;
+    pipe.init(a.packed + (kHalf ? kHBlobOffset : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
 
-    f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators
+    f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators (the first NT of them)
     float* const ws = a.train_workspace;
 
     // Inference: a wave owns a ray, walks its chunks in order and composites as it goes.
@@ -317,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
             LazyNorm norm;
             f32x4 out[4];
-            if (kHalf) {
+            if constexpr (kHalf) {
                 HMoments mom;
                 // split-precision MLP: X and Y swap roles layer by layer (no copy-back)
                 const float eps = 1e-5f * (float)(1 << (kWScaleLog2 + kXScaleLog2)) *
@@ -360,6 +478,27 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                     racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
                     racc.seg_m = s1.x, racc.seg_s = s1.y, dist = s1.z;
                 }
+            } else if constexpr (NT < 16) {
+                // ---- a narrow network at its own cost (nerf_layout.h: Narrow<NT>) ----
+                Moments mom;
+#pragma unroll
+                for (int t = kStagesL0; t < N::kKGroups0; ++t) X[t] = f32x4{0.f, 0.f, 0.f, 0.f};    // zero-padded k-groups
+                load_bias_n<NT>(small, g, Y);
+                layer_fused_n<NT, N::kKGroups0, false, kTrain>(pipe, X, Y, norm, mom);
+                norm = finish_moments<kTrain, Moments, NT>(mom, X, small, g, nullptr, nullptr, ka.norm);
+#pragma unroll 1
+                for (int L = 1; L <= 4; ++L) {
+                    const float* small_l = small + L * kSmallPerLayerLds;
+                    load_bias_n<NT>(small_l, g, Y);
+                    layer_fused_n<NT, NT, true, kTrain>(pipe, X, Y, norm, mom);
+                    norm = finish_moments<kTrain, Moments, NT>(mom, X, small_l, g, nullptr, nullptr, ka.norm);
+                }
+                {
+                    const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) out[T] = b[T];
+                }
+                layer_out_n<NT, kTrain>(pipe, X, out, norm);
             } else {
             Moments mom;
             // ---- layer 0: 96 -> 256 ----
@@ -531,9 +670,34 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         return;
     }
     const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
-    if (e >= kImageFloats) return;
+    if (e >= kPackedFloats || (e >= kImageFloats && e < kWideFloats)) return;      // (the bounds block's four floats)
     float v = 0.f;
-    if (e < kBlobFloats) {
+    if (e >= kNarrow8Offset) {
+        // the narrow fp32 image of the width this network runs at (nerf_layout.h: Narrow<NT>); the other one stays unwritten
+        const int nt = tiles_for(pa.hidden);
+        const bool eight = e < kNarrow4Offset;
+        if (nt != (eight ? 8 : 4)) return;
+        const int eb = e - (eight ? kNarrow8Offset : kNarrow4Offset);
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int quad = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int row = lane & 15, g = lane >> 4;
+        const int s0 = eight ? Narrow<8>::kStages0 : Narrow<4>::kStages0;
+        const int sh = eight ? Narrow<8>::kStagesHid : Narrow<4>::kStagesHid;
+        if (stage < s0) {                                           // layer 0: quads numbered k-group * NT + out tile
+            const int qq = stage * 16 + quad, k = qq / nt, T = qq % nt;
+            v = k < kStagesL0 ? pa.w0(16 * T + row, k, g, r) : 0.f;
+        } else if (stage < s0 + 4 * sh) {                           // layers 1..4
+            const int L = 1 + (stage - s0) / sh;
+            const int qq = ((stage - s0) % sh) * 16 + quad, k = qq / nt, T = qq % nt;
+            v = pa.wh(L, 16 * T + row, 16 * k + 4 * g + r);
+        } else {                                                    // layer 5: stage s = k-groups 4 s .. 4 s + 3 x 4 out tiles
+            const int s5 = stage - (s0 + 4 * sh);
+            const int t = 4 * s5 + quad / 4, T = quad % 4;
+            v = pa.w5(16 * T + row, 16 * t + 4 * g + r);
+        }
+    } else if (e < kBlobFloats) {
         const int stage = e / kStageFloats;
         const int in_stage = e - stage * kStageFloats;
         const int quad = in_stage / kQuadFloats;
@@ -717,7 +881,7 @@ int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t en
         pa.p[i] = params[i];
     }
     pa.packed = packed;
-    const int threads = 256, blocks = (kImageFloats + threads - 1) / threads + 1;     // + the bounds block
+    const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads + 1;    // + the bounds block
     hipLaunchKernelGGL(nerf_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, pa);
     return nerf_common::check_hip(hipGetLastError(), "pack_weights launch");
 }
@@ -773,12 +937,20 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
          {nerf_render_fwd_kernel<false, true, false>, nerf_render_fwd_kernel<false, true, true>}},
         {{nerf_render_fwd_kernel<true, false, false>, nullptr},
          {nerf_render_fwd_kernel<true, true, false>, nullptr}}};
-    static unsigned done[2][2][2] = {};
+    // narrow networks at their own cost (fp32 inference): [NT 8 | 4][per_sample]; every other mode runs a narrow
+    // network zero-padded in the full-width kernels
+    static const Kernel narrow[2][2] = {
+        {nerf_render_fwd_kernel<false, false, false, 8>, nerf_render_fwd_kernel<false, false, true, 8>},
+        {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
+    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {};
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
-    const Kernel kernel = kernels[train][half][ps];
+    const int nt = tiles_for(shape_of(a).hidden);
+    const bool is_narrow = !train && !half && nt < 16;
+    const Kernel kernel = is_narrow ? narrow[nt == 4][ps] : kernels[train][half][ps];
+    unsigned* const done_mask = is_narrow ? &done_narrow[nt == 4][ps] : &done[train][half][ps];
     const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
-    rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, &done[train][half][ps]);
+    rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;
     int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs)
     if (grid > ka.groups) grid = ka.groups;
