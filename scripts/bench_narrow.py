@@ -21,5 +21,5 @@ for hidden, enc in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10)
         torch.cuda.synchronize()
         ms, n = _lib.timing_read(reset=True); _lib.timing(False)
     tf = 640000 * 127 * flop / (ms * 1e-3) / 1e12
-    print(f"hidden {hidden:3d} enc {enc:2d}: kernel {ms:8.2f} ms  {640000 * 128 / ms / 1e3:.3e} ray-samples/s  "
+    print(f"hidden {hidden:3d} enc {enc:2d}: kernel {ms:8.2f} ms  {640000 * 128 / (ms * 1e-3):.3e} ray-samples/s  "
           f"{tf:6.1f} TFLOP/s on {flop} FLOP/sample = {tf / 157.3:.3f} of the fp32 MFMA peak", flush=True)
