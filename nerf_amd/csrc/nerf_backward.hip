@@ -161,6 +161,83 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
         ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
 }
 
+// The same chain for a network that trains at 8 register tiles per sample (hidden_size <= 128, fp32 arithmetic;
+// nerf_device.h: train_tiles): saved rows 128 wide, the transposed narrow image (nerf_layout.h: kNarrowBwd8Offset:
+// 2 stages for layer 5, 4 per hidden layer).  The wave-ordered gamma / beta adds of a layer ride on the four stage
+// barriers of the hidden loop that follows it; layer 0's have no such loop behind them (the next item opens with
+// the two-stage layer-5 loop), so they take their turns at the end of the item, a barrier apart.
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_n8_kernel(const BwdArgs ba) {
+    constexpr int NT = 8, kTileN = 256 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* const ws = a.train_workspace;
+    float* const gb = (float*)(smem + kRingBytes + kSmallLdsBytes);
+
+    {
+        stage_small_image(a.packed + kBlobFloats, (float*)(smem + kRingBytes));
+        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+    }
+    const float* small = (const float*)(smem + kRingBytes);
+
+    WeightPipe<kNarrowBwd8Stages> pipe;
+    pipe.init(a.packed + kNarrowBwd8Offset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
+        const int64_t sp = tile * 16 + j;
+        {
+            const float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const f32x4 d = *(const f32x4*)(drow + T * 16);
+                act[4 * T] = d.x, act[4 * T + 1] = d.y, act[4 * T + 2] = d.z, act[4 * T + 3] = d.w;
+            }
+        }
+        // ---- layer 5: dX = W5^T dOut (4 k-groups of padded outputs x 8 in tiles: 2 stages) ----
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 xh[16];
+        float rstd;
+        layer_wide_n<NT, 4>(pipe, acc, act,
+                            BwdHookN<NT>{turn, ws + ba.L.xhat[4] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[4] + sp, xh, rstd});
+        // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY (8 k-groups x 8 in tiles: 4 stages) ----
+#pragma unroll 1
+        for (int L = 4; L >= 1; --L) {
+            layer_norm_relu_bwd<false, NT>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
+                                           ws + ba.L.dy[L] + tile_lane_base(sp, g, kTileN), gb + L * 2 * kHidden, turn, ba.inv_n);
+#pragma unroll
+            for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            layer_wide_n<NT, NT>(pipe, acc, act,
+                                 BwdHookN<NT>{turn, ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[L - 1] + sp,
+                                              xh, rstd});
+        }
+        layer_norm_relu_bwd<false, NT>(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + tile_lane_base(sp, g, kTileN), gb, turn,
+                                       ba.inv_n);
+        for (int t = 0; t < kWavesPerWg; ++t) {       // layer 0's partials, in wave order
+            __syncthreads();
+            turn(t);
+        }
+        turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+}
+
 // vector-memory operations issued between the DMA of a loop's stage 1 and its first hand-overs: the 17
 // x_hat / 1/std loads (layer 5's loop), or the 16 dY saves of the LayerNorm backward + those 17 loads
 constexpr int kYoungerL5 = 17, kYoungerHidden = 33;
@@ -336,6 +413,27 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
     }
 }
 
+// ... and for a network that trains at 8 register tiles per sample (saved rows 128 wide; shapes: nerf_backward_common.h)
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_n8_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
+                      ba.data_grid, 8};
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kBlobFloats;
+    if (job < 4) {
+        wgrad_body_ring<ShapeHidN8, kInputAffineRelu>(jb, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * 128,
+                                                      ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * 128,
+                                                      small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
+                                                      kSlabB + (job + 1) * kHidden);
+    } else if (job == 4) {
+        wgrad_body_ring<ShapeL0N8, kInputRaw>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
+    } else {
+        wgrad_body_ring<ShapeL5N8, kInputAffineRelu>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                                     kSlabW5, kSlabB + 5 * kHidden);
+    }
+}
+
 // The same launch in the split-precision training mode (f16-pair operands, see wgrad_body_ring).
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -459,7 +557,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.d_raw = args->d_raw;
     ba.intervals = a.num_samples - 1;
     ba.chunks = (ba.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
-    ba.L = make_train_layout(a.n_rays, ba.chunks);
+    const int tt = train_tiles(shape_of(a).hidden, a.precision);      // 8: a narrow network in fp32 arithmetic, at its own cost
+    ba.L = make_train_layout(a.n_rays, ba.chunks, 16 * tt);
     ba.groups = ba.L.mp / 16 / kWavesPerWg;                 // (padded ray, chunk) items / 4 waves
     const int64_t slots = ba.L.mp / 16 / ba.chunks;         // padded rays
     ba.grad = args->grad;
@@ -492,6 +591,13 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad_h);
     if (rc) return rc;
+    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0;
+    if (tt == 8) {
+        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n8_kernel, kBwdLdsBytes, device, &done_data_n8);
+        if (rc) return rc;
+        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n8);
+        if (rc) return rc;
+    }
     int64_t grid = (int64_t)cus * 2;
     if (grid > ba.groups) grid = ba.groups;
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;
@@ -503,10 +609,13 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                            dim3(256), 0, st, ba);
     if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
+    else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     const int wgrad_jobs = 6;
     const bool wgrad_half = half;
-    if (wgrad_half)
+    if (tt == 8)
+        hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+    else if (wgrad_half)
         hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
     else
         hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);

@@ -40,7 +40,8 @@ struct GammaBetaTurn {
 // runs under this layer's MFMAs instead of in front of the LayerNorm arithmetic.  (Stage 1, not 0:
 // the loads then sit behind one stage's DMA in the vmcnt queue and the next stage's counted wait
 // retires them only after a whole stage of MFMAs.)
-struct BwdHook {
+template <int NT = 16>
+struct BwdHookN {
     GammaBetaTurn& turn;
     const float* xhat_row;      // this lane's 4 features of register tile 0 (tile-major rows: nerf_device.h)
     const float* rstd_ptr;
@@ -50,18 +51,19 @@ struct BwdHook {
         turn(t);
         if (t == 1) {
 #pragma unroll
-            for (int T = 0; T < 16; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
+            for (int T = 0; T < NT; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
             rstd = *rstd_ptr;
         }
     }
 };
+typedef BwdHookN<16> BwdHook;
 
 // LayerNorm + ReLU backward for hidden layer L on the register tile.
 //   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
 //   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
 //   kScaled (split-precision chain): acc holds dL/dx times the per-sample power of two `unscale`
 //   undoes (the B operands were scaled into the f16 range, the weights carry 2^kWScaleLog2)
-template <bool kScaled = false>
+template <bool kScaled = false, int NT = 16>
 __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
                                                     f32x4 (&acc)[16], float (&act)[64],
                                                     const f32x4 (&xh)[16], float rstd,
@@ -92,6 +94,7 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     };
     // beta / gamma gradients: sums over the 16 samples of a row, lane j keeps tile j.
     float kept[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    static_assert(NT == 16 || !kScaled, "the split-precision chain runs at full width");
     if constexpr (kScaled) {
         // split-precision chain (VALU-paced): a reduce-scatter butterfly (nerf_device.h: scatter_level8 / 4 /
         // take) applied as the tiles come: t, t + 8, t + 4, t + 12 — 2 DPP adds per value
@@ -112,7 +115,7 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
         // longer live ranges cost this kernel 120 B more spills than its shorter VALU phase gains
         // (3.88 against 3.81 ms per 4096 x 64 step)
 #pragma unroll
-        for (int T = 0; T < 16; ++T) {
+        for (int T = 0; T < NT; ++T) {
             float v[8];
             tile(T, v);
 #pragma unroll
@@ -129,7 +132,7 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     const float m1 = group_sum(s1) * inv_n;
     const float m2 = group_sum(s2) * inv_n;
 #pragma unroll
-    for (int T = 0; T < 16; ++T) {
+    for (int T = 0; T < NT; ++T) {
         f32x4 dy;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -326,10 +329,11 @@ constexpr int kKs = 32;                          // samples per LDS tile
 //   kMapGrid: 2 x 2 waves of TO x TI tiles each;  kMapRows: wave w takes out tiles TO w .. TO w + TO - 1 and
 //   all TI in tiles;  kMapCols: all TO out tiles, in tiles TI w .. TI w + TI - 1
 constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2;
-template <int OUT_W, int IN_W, int TO, int TI, int MAP>
+template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W>
 struct WgradShape {
     static constexpr int kMap = MAP;
     static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
+    static constexpr int kSlabStride = SLAB_STRIDE;            // floats between two rows of the product in the partial slab
     static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
     static constexpr int kTileBytes = kDyBytes + kXBytes;
     static constexpr int kPieces = kTileBytes / 1024;          // 1 KiB LDS-DMA pieces per tile
@@ -339,6 +343,15 @@ struct WgradShape {
 typedef WgradShape<kHidden, kEncIn, 2, 3, kMapRows> ShapeL0;        // waves: out tiles 2w..2w+1, all 3 in tiles
 typedef WgradShape<kHidden, kHidden, 4, 4, kMapGrid> ShapeHid;       // waves 2x2: 4x4 tiles each
 typedef WgradShape<kOutPad, kHidden, 2, 2, kMapCols> ShapeL5;        // waves: both out tiles, in tiles 2w..2w+1
+// A network that trains at 8 register tiles per sample (hidden_size <= 128, fp32 arithmetic): saved rows 128 wide, the
+// products land in the same full-width slab (row stride of the full-width tensors), so the reduce kernel does not change.
+typedef WgradShape<128, 128, 2, 2, kMapGrid, kHidden> ShapeHidN8;    // waves 2x2: 2x2 tiles each
+typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden> ShapeL5N8; // waves: both out tiles, in tile w
+// layer 0 (128 x 96 = 4 x 3 tiles): waves 0 and 1 take out tiles 0..1 and 2..3 with all three in tiles; waves 2 and 3
+// run the same code on out tiles 4..7, which the 128-wide dY does not have — they read whatever lies behind it in the
+// ring slot and write rows 128..255 of the full-width slab, which the reduce kernel never reads for such a network
+// (an odd out-tile count per wave is not an option: the A operand sets ping-pong slot by slot).
+typedef WgradShape<128, kEncIn, 2, 3, kMapRows> ShapeL0N8;
 
 // ---------------------------------------------------------------------------------------------
 // The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
@@ -427,7 +440,7 @@ constexpr int kRingSlots = 4;
 // Narrow operands (the 96 encoded inputs, the 64 padded outputs) are row-major [16][W] and copied as they are.
 template <int W>
 struct SlotLayout {
-    static constexpr bool kTiled = W == kHidden;
+    static constexpr bool kTiled = W == kHidden || W == 128;      // (96 and 64 are the row-major operands)
     static constexpr int kPieces = kRingStep * W * 4 / 1024;
     static constexpr int kBytes = kPieces * 1024;
     // word offset of (sample 8 kk + jj, feature 32 X + i) = lane(kk, i, jj >> 2) + step(jj, X)
@@ -876,7 +889,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[w_off + (32 * (out0 + a) + row) * Sh::kInW + 32 * (in0 + b) + col] = acc[a][b][r] * un_scale;
+                slab[w_off + (32 * (out0 + a) + row) * Sh::kSlabStride + 32 * (in0 + b) + col] = acc[a][b][r] * un_scale;
             }
 #pragma unroll
     for (int a = 0; a < Sh::kTo; ++a) {

@@ -72,20 +72,29 @@ struct TrainLayout {
     int64_t total;              // floats
 };
 
-__host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chunks) {
+// `width`: features per saved x_hat / dY row — 256, or 128 when a narrow network (hidden_size <= 128) trains at its
+// own cost (fp32 arithmetic; nerf_layout.h: Narrow<8>): half the bytes of the step's dominant tensors.  The
+// workspace the caller allocates is always sized for 256 (nerf_hip_train_workspace_bytes has no shape argument).
+__host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chunks, int width = kHidden) {
     TrainLayout t;
     const int64_t rays4 = (n_rays + 3) / 4 * 4;
     t.mp = rays4 * chunks * 16;
     int64_t off = 0;
     t.h = off; off += t.mp * kEncIn;
-    for (int i = 0; i < 5; ++i) { t.dy[i] = off; off += t.mp * kHidden; }
+    for (int i = 0; i < 5; ++i) { t.dy[i] = off; off += t.mp * width; }
     t.dy5 = off; off += t.mp * kOutPad;
-    for (int i = 0; i < 5; ++i) { t.xhat[i] = off; off += t.mp * kHidden; }
+    for (int i = 0; i < 5; ++i) { t.xhat[i] = off; off += t.mp * width; }
     for (int i = 0; i < 5; ++i) { t.rstd[i] = off; off += t.mp; }
     t.out = off; off += t.mp * kOutPad;
     t.comp = off; off += t.mp * 4;
     t.total = off;
     return t;
+}
+// register tiles per sample the TRAINING kernels of a launch run at: 8 for a narrow network in fp32 arithmetic
+// (hidden_size <= 128; <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator
+// tiles), else 16 (every network in split-precision arithmetic runs zero-padded in the full-width kernels)
+__host__ __device__ inline int train_tiles(int hidden, int precision) {
+    return precision == NERF_HIP_PRECISION_FP32 && hidden <= 128 ? 8 : 16;
 }
 
 // Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the
@@ -106,8 +115,8 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
 constexpr int kTileFloats = 16 * kHidden;       // one 16-sample tile of a 256-wide row tensor
 constexpr int kTileT = 256;                     // floats between two register tiles T of a lane
 __host__ __device__ inline int tile_lane_word(int s, int g) { return g * 64 + s * 4; }
-__host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g) {      // this lane's f32x4 of register tile 0
-    return (sp >> 4) * kTileFloats + tile_lane_word((int)(sp & 15), g);
+__host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g, int tile_floats = kTileFloats) {   // this lane's f32x4 of register tile 0
+    return (sp >> 4) * tile_floats + tile_lane_word((int)(sp & 15), g);     // (tile_floats = 16 x row width)
 }
 
 // The network's shape from an argument block (0 = the defaults 256 / 96), and what the LayerNorms need of it:
@@ -281,6 +290,53 @@ __device__ __forceinline__ void layer_wide(Pipe& pipe, f32x4 (&acc)[16], const f
             // keep groups apart: merged groups would re-issue the reads just before their use
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+}
+
+// The same pipeline for a NARROW product (nerf_layout.h: Narrow<NT>): NT accumulator tiles, KG k-groups, a stage =
+// 16 quads = 16 / NT k-groups; group p (two quads, 8 MFMAs) works on k-group p / (NT / 2) and the tile pair
+// 2 (p % (NT / 2)).  layer_wide is this function at NT = 16 (kept as its own copy: the full-width kernels' code
+// does not move).  hook(s) runs once per stage, after the stage's barrier.
+template <int NT, int KG, class Pipe, class Hook = NoHook>
+__device__ __forceinline__ void layer_wide_n(Pipe& pipe, f32x4 (&acc)[16], const float (&act)[64], Hook hook = Hook()) {
+    constexpr int kPerK = NT / 2, kGroups = KG * kPerK;
+    static_assert(kGroups % 8 == 0, "a product ends on a stage boundary");
+    f32x4 a[2][2];
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    const f32x4* st = pipe.open_stage();
+    a[0][0] = st[0];
+    a[0][1] = st[64];
+    pipe.prefetch_next();
+    hook(0);
+#pragma unroll
+    for (int p = 0; p < kGroups; ++p) {
+        const int k = p / kPerK, lp = p % kPerK, tp = p % 8;
+        const int T0 = 2 * lp, T1 = 2 * lp + 1;
+        const float b0 = act[4 * k], b1 = act[4 * k + 1], b2 = act[4 * k + 2], b3 = act[4 * k + 3];
+        const int cur = p & 1, nxt = cur ^ 1;
+        const f32x4 a0 = a[cur][0], a1 = a[cur][1];
+        acc[T0] = mfma4(a0.x, b0, acc[T0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tp < 7) {
+            a[nxt][0] = st[(2 * tp + 2) * 64];
+            a[nxt][1] = st[(2 * tp + 3) * 64];
+        } else if (p + 1 < kGroups) {
+            st = pipe.open_stage();
+            a[nxt][0] = st[0];
+            a[nxt][1] = st[64];
+            pipe.prefetch_next();
+            hook((p + 1) / 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[T1] = mfma4(a1.x, b0, acc[T1]);
+        acc[T0] = mfma4(a0.y, b1, acc[T0]);
+        acc[T1] = mfma4(a1.y, b1, acc[T1]);
+        acc[T0] = mfma4(a0.z, b2, acc[T0]);
+        acc[T1] = mfma4(a1.z, b2, acc[T1]);
+        acc[T0] = mfma4(a0.w, b3, acc[T0]);
+        acc[T1] = mfma4(a1.w, b3, acc[T1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }

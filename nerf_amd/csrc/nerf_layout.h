@@ -105,7 +105,15 @@ struct Narrow {
 static_assert(Narrow<16>::kStages == kNumStages, "NT = 16 is the full-width image");
 constexpr int kNarrow8Offset = kWideFloats;                                  // 16-byte aligned (kWideFloats % 4 == 0)
 constexpr int kNarrow4Offset = kNarrow8Offset + Narrow<8>::kFloats;
-constexpr int kPackedFloats = kNarrow4Offset + Narrow<4>::kFloats;
+// ... and the TRANSPOSED narrow fp32 image for the data gradient of a network that trains at 8 register tiles
+// (hidden_size <= 128, fp32 arithmetic): as the full-width transposed image, last layer first, k = OUT features,
+// accumulator tiles = IN tiles; quads numbered k-group * 8 + in tile, 16 to a stage:
+//   stages 0..1  : layer 5 (4 k-groups of padded outputs x 8 in tiles)
+//   stages 2..17 : layers 4, 3, 2, 1 (8 k-groups x 8 in tiles = 4 stages each)
+// quad (k-group tout, in tile Tin): [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i]
+constexpr int kNarrowBwd8Stages = 2 + 4 * 4;
+constexpr int kNarrowBwd8Offset = kNarrow4Offset + Narrow<4>::kFloats;
+constexpr int kPackedFloats = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFloats;
 static_assert(kWideFloats % 4 == 0, "narrow images start 16-byte aligned");
 // register tiles a network of `hidden` features needs, rounded up to an instantiated width
 __host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16); }

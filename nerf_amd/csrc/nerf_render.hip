@@ -349,7 +349,8 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
-    static_assert(NT == 16 || (!kTrain && !kHalf), "narrow instantiations: fp32 inference");
+    static_assert(NT == 16 || !kHalf, "narrow instantiations: fp32 arithmetic");
+    static_assert(NT != 4 || !kTrain, "training runs at 8 or 16 register tiles (nerf_device.h: train_tiles)");
     typedef Narrow<NT> N;
     typedef WeightPipe<N::kStages> Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
-            float* const xrow = kTrain ? ws + tile_lane_base(sp, g) : nullptr;     // + ka.save.xhat[L] (tile-major)
+            float* const xrow = kTrain ? ws + tile_lane_base(sp, g, 256 * NT) : nullptr;     // + ka.save.xhat[L] (tile-major)
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
             LazyNorm norm;
@@ -485,13 +486,14 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 for (int t = kStagesL0; t < N::kKGroups0; ++t) X[t] = f32x4{0.f, 0.f, 0.f, 0.f};    // zero-padded k-groups
                 load_bias_n<NT>(small, g, Y);
                 layer_fused_n<NT, N::kKGroups0, false, kTrain>(pipe, X, Y, norm, mom);
-                norm = finish_moments<kTrain, Moments, NT>(mom, X, small, g, nullptr, nullptr, ka.norm);
+                norm = finish_moments<kTrain, Moments, NT>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0], ka.norm);
 #pragma unroll 1
                 for (int L = 1; L <= 4; ++L) {
                     const float* small_l = small + L * kSmallPerLayerLds;
                     load_bias_n<NT>(small_l, g, Y);
                     layer_fused_n<NT, NT, true, kTrain>(pipe, X, Y, norm, mom);
-                    norm = finish_moments<kTrain, Moments, NT>(mom, X, small_l, g, nullptr, nullptr, ka.norm);
+                    norm = finish_moments<kTrain, Moments, NT>(mom, X, small_l, g, xrow + ka.save.xhat[L],
+                                                               rstd_p + ka.save.rstd[L], ka.norm);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
@@ -672,11 +674,29 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
     const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     if (e >= kPackedFloats || (e >= kImageFloats && e < kWideFloats)) return;      // (the bounds block's four floats)
     float v = 0.f;
-    if (e >= kNarrow8Offset) {
-        // the narrow fp32 image of the width this network runs at (nerf_layout.h: Narrow<NT>); the other one stays unwritten
-        const int nt = tiles_for(pa.hidden);
+    if (e >= kNarrowBwd8Offset) {
+        // transposed narrow image (nerf_layout.h): written for every network that can train at 8 register tiles
+        if (pa.hidden > 128) return;
+        const int eb = e - kNarrowBwd8Offset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int quad = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int i = lane & 15, g = lane >> 4;
+        if (stage < 2) {
+            const int qq = stage * 16 + quad, tout = qq / 8, tin = qq % 8;
+            v = pa.w5(16 * tout + 4 * g + r, 16 * tin + i);
+        } else {
+            const int L = 4 - (stage - 2) / 4;                       // 4, 3, 2, 1
+            const int qq = ((stage - 2) % 4) * 16 + quad, tout = qq / 8, tin = qq % 8;
+            v = pa.wh(L, 16 * tout + 4 * g + r, 16 * tin + i);
+        }
+    } else if (e >= kNarrow8Offset) {
+        // the narrow fp32 images this network can run at (nerf_layout.h: Narrow<NT>): 8 register tiles for
+        // hidden_size <= 128 (inference at 65 .. 128, training at <= 128), 4 for <= 64 (inference)
         const bool eight = e < kNarrow4Offset;
-        if (nt != (eight ? 8 : 4)) return;
+        const int nt = eight ? 8 : 4;
+        if (pa.hidden > 16 * nt) return;
         const int eb = e - (eight ? kNarrow8Offset : kNarrow4Offset);
         const int stage = eb / kStageFloats;
         const int in_stage = eb - stage * kStageFloats;
@@ -911,9 +931,10 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.a = a;
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
-    ka.save = make_train_layout(a.n_rays, ka.chunks);
-    ka.norm = norm_divisor(shape_of(a).hidden);
     const bool train = a.train_workspace != nullptr;
+    const int tt = train_tiles(shape_of(a).hidden, a.precision);       // training: 8 or 16 register tiles per sample
+    ka.save = make_train_layout(a.n_rays, ka.chunks, 16 * tt);
+    ka.norm = norm_divisor(shape_of(a).hidden);
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
     if (train && a.out_t != nullptr)
@@ -937,18 +958,19 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
          {nerf_render_fwd_kernel<false, true, false>, nerf_render_fwd_kernel<false, true, true>}},
         {{nerf_render_fwd_kernel<true, false, false>, nullptr},
          {nerf_render_fwd_kernel<true, true, false>, nullptr}}};
-    // narrow networks at their own cost (fp32 inference): [NT 8 | 4][per_sample]; every other mode runs a narrow
-    // network zero-padded in the full-width kernels
+    // narrow networks at their own cost (fp32 arithmetic): inference [NT 8 | 4][per_sample], training forward at 8;
+    // split-precision launches run a narrow network zero-padded in the full-width kernels
     static const Kernel narrow[2][2] = {
         {nerf_render_fwd_kernel<false, false, false, 8>, nerf_render_fwd_kernel<false, false, true, 8>},
         {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
-    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {};
+    static const Kernel narrow_train = nerf_render_fwd_kernel<true, false, false, 8>;
+    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_train = 0;
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
-    const int nt = tiles_for(shape_of(a).hidden);
-    const bool is_narrow = !train && !half && nt < 16;
-    const Kernel kernel = is_narrow ? narrow[nt == 4][ps] : kernels[train][half][ps];
-    unsigned* const done_mask = is_narrow ? &done_narrow[nt == 4][ps] : &done[train][half][ps];
+    const int nt = train ? tt : tiles_for(shape_of(a).hidden);
+    const bool is_narrow = !half && nt < 16;
+    const Kernel kernel = is_narrow ? (train ? narrow_train : narrow[nt == 4][ps]) : kernels[train][half][ps];
+    unsigned* const done_mask = is_narrow ? (train ? &done_narrow_train : &done_narrow[nt == 4][ps]) : &done[train][half][ps];
     const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;
