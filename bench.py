@@ -188,14 +188,16 @@ def cpu_baseline():
             "config1_100x100x64": cpu_baseline_small(best["cores"])}
 
 
-def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32"):
+def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32", hidden=256, enc=32):
     """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
-    backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1."""
+    backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1.
+    `hidden` / `enc`: the constructor's hidden_size / encoding_size (nerf/model.py:471-475); a network of
+    hidden_size <= 128 trains at its own cost in fp32 arithmetic (kernels at 8 register tiles per sample)."""
     from nerf_amd import NeRF
     from nerf_amd.optim import Adam
     from nerf_amd.loss import mse_and_grad
     torch.manual_seed(0)
-    model = NeRF().to(dev)
+    model = NeRF(hidden_size=hidden, encoding_size=enc).to(dev)
     model.train_precision = train_precision
     opt = Adam(model.parameters(), lr=1e-4)                               # as nerf_amd/trainer.py
     o, d = torch.randn(rays, 3, device=dev), torch.randn(rays, 3, device=dev)
@@ -216,7 +218,15 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
         step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    tflops = 3 * FLOP_PER_SAMPLE * rays * (samples - 1) / dt / 1e12
+    flop = 2 * (3 * enc * hidden + 4 * hidden * hidden + 54 * hidden)
+    tflops = 3 * flop * rays * (samples - 1) / dt / 1e12
+    if hidden != 256:
+        return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam, hidden_size={hidden}, "
+                            f"encoding_size={enc} ({flop} FLOP per sample)",
+                "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt, "tflops_fwd_dgrad_wgrad": tflops,
+                "arithmetic": ("fp32 MFMA forward and data gradient, bf16-triple weight gradient, all at 8 register tiles "
+                               "per sample with 128-wide saved rows (the network's own cost)" if train_precision == "fp32"
+                               else "f16 pairs, zero-padded in the full-width kernels (no narrow instantiation)")}
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
@@ -889,6 +899,7 @@ def main():
             }
             line["train_step"] = train_step_timing(dev)
             line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
+            line["train_step_hidden128"] = train_step_timing(dev, hidden=128)
             line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
             line["legacy_train_step"] = legacy_train_step_timing(dev)

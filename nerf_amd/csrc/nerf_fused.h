@@ -192,10 +192,14 @@ typedef MomentsPk HMoments;
 // A 16-out-tile layer over KB k blocks.  Stage order (half, m): out tiles 0..7 are complete after
 // the first KB stages, so their moments ride in the second half; the B operands of block m + 1 are
 // built (normalise tile by tile, then split) during stage (0, m).
-template <int KB, bool kNormIn, bool kTrain, int kOrder = kOrderNormRelu, class Pipe>
+// NT = 8 (a narrow network, nerf_layout.h: kNarrowH8Offset): ONE half — a stage = the eight out tiles of k block m —
+// so every tile completes in the last stage and the moments ride there, a unit behind.
+template <int KB, bool kNormIn, bool kTrain, int kOrder = kOrderNormRelu, int NT = 16, class Pipe>
 __device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
                                               const LazyNorm& norm, HMoments& mom) {
-    constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
+    static_assert(NT == 16 || NT == 8, "out tiles in halves of eight");
+    constexpr int kHalves = NT / 8;
+    constexpr int kStages = kHalves * KB, kUnits = 8 * kStages;
     h8 bhi[KB], blo[KB];
     if (kNormIn) {
         normalize_tile<kTrain, kPackNorm, kOrder>(in[0], norm, 0);
@@ -259,7 +263,7 @@ __device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4
                 }
                 if (i >= 1 && i <= 4) interleave_2<4>();
             }
-            if (half == 1) {
+            if (kHalves == 2 && half == 1) {
                 // tiles 0..7 (finished in the first half), spread over the second half's stages
 #pragma unroll
                 for (int T2 = 0; T2 < 8; ++T2) {
@@ -269,15 +273,15 @@ __device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4
                         if (s + 1 < kStages) interleave_2<2>();
                     }
                 }
-                if (s + 1 == kStages && i >= 1) {        // tile finished one unit ago
-                    mom.template add<kOrder>(out[T - 1]);
-                    interleave_2<2>();
-                }
+            }
+            if (s + 1 == kStages && i >= 1) {            // tile finished one unit ago
+                mom.template add<kOrder>(out[T - 1]);
+                interleave_2<2>();
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    mom.template add<kOrder>(out[15]);
+    mom.template add<kOrder>(out[NT - 1]);
     __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
 }
 

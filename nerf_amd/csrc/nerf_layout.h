@@ -113,7 +113,12 @@ constexpr int kNarrow4Offset = kNarrow8Offset + Narrow<8>::kFloats;
 // quad (k-group tout, in tile Tin): [lane (i, g)][r] = W[16 tout + 4 g + r][16 Tin + i]
 constexpr int kNarrowBwd8Stages = 2 + 4 * 4;
 constexpr int kNarrowBwd8Offset = kNarrow4Offset + Narrow<4>::kFloats;
-constexpr int kPackedFloats = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFloats;
+// ... and the split-precision ("f16x3") forward image at 8 register tiles (inference of a network with hidden_size
+// <= 128): the slab format of the full-width f16 image with ONE half — wide layers: stage = k block m (3 for layer 0,
+// 4 for layers 1..4), pair i = out tile i; layer 5: stage s, pair i = (k block 2 s + (i >> 2), out tile i & 3), 2 stages
+constexpr int kNarrowH8Stages = 3 + 4 * 4 + 2;
+constexpr int kNarrowH8Offset = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFloats;
+constexpr int kPackedFloats = kNarrowH8Offset + kNarrowH8Stages * kStageFloats;
 static_assert(kWideFloats % 4 == 0, "narrow images start 16-byte aligned");
 // register tiles a network of `hidden` features needs, rounded up to an instantiated width
 __host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16); }

@@ -276,10 +276,11 @@ __device__ __forceinline__ void layer_out_n(Pipe& pipe, f32x4 (&in)[16], f32x4 (
 
 // Layer 5 (256 -> 64 padded) of the split-precision path: 4 stages of two k blocks x 4 out tiles;
 // block m + 1 is built during the four units of block m.
-template <bool kTrain>
-__device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
+template <bool kTrain, int NT = 16, class Pipe>
+__device__ __forceinline__ void layer_out_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4],
                                             const LazyNorm& norm) {
-    constexpr int kUnits = 8 * kStagesL5;
+    constexpr int kStages5 = NT / 4, kBlocks = NT / 2;      // (k block, out tile) pairs: 8 to a stage
+    constexpr int kUnits = 8 * kStages5;
     h8 bh[2], bl[2];
     normalize_tile<kTrain, kPackNorm>(in[0], norm, 0);
     normalize_tile<kTrain, kPackNorm>(in[1], norm, 1);
@@ -296,7 +297,7 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
     }
     pipe.prefetch_next();
 #pragma unroll
-    for (int s = 0; s < kStagesL5; ++s) {
+    for (int s = 0; s < kStages5; ++s) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int U = 8 * s + i, set = U % kSets;
@@ -312,18 +313,18 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
                 al[pset] = st[(2 * ip + 1) * 64];
                 if (ip == 0) pipe.prefetch_next();
             }
-            if (q == 1 && m + 1 < 8) {
+            if (q == 1 && m + 1 < kBlocks) {
                 ga = norm.gam[tb];
                 be = norm.bet[tb];
             }
-            if (q == 3 && m + 2 < 8) {
+            if (q == 3 && m + 2 < kBlocks) {
                 ga = norm.gam[ta + 2];
                 be = norm.bet[ta + 2];
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[T] = mfma_h(ah[set], bl[pb], acc[T]);
             acc[T] = mfma_h(al[set], bh[pb], acc[T]);
-            if (m + 1 < 8) {
+            if (m + 1 < kBlocks) {
                 if (q == 0) normalize_tile<kTrain, kPackNorm>(in[ta], norm, ta, ga, be);
                 if (q == 1) split4(in[ta], nh[0], nh[1], nl[0], nl[1]);
                 if (q == 2) normalize_tile<kTrain, kPackNorm>(in[tb], norm, tb, ga, be);
@@ -349,8 +350,9 @@ __device__ __forceinline__ void layer_out_h(FwdPipe& pipe, f32x4 (&in)[16], f32x
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
 __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
-    static_assert(NT == 16 || !kHalf, "narrow instantiations: fp32 arithmetic");
-    static_assert(NT != 4 || !kTrain, "training runs at 8 or 16 register tiles (nerf_device.h: train_tiles)");
+    static_assert(NT != 4 || (!kTrain && !kHalf), "4 register tiles: fp32 inference only (training and the "
+                                                  "split-precision arithmetic run at 8 or 16)");
+    static_assert(NT == 16 || !(kTrain && kHalf), "split-precision training runs at full width (nerf_device.h: train_tiles)");
     typedef Narrow<NT> N;
     typedef WeightPipe<N::kStages> Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     const float* small = (const float*)(smem + kRingBytes);
 
     Pipe pipe;
-    pipe.init(a.packed + (kHalf ? kHBlobOffset : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
+    pipe.init(a.packed + (kHalf ? (NT == 16 ? kHBlobOffset : kNarrowH8Offset)
+                                : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
@@ -449,29 +452,29 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 }
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) X[t] = X[t] * (float)(1 << kXScaleLog2);
-                load_bias16(small, g, Y);
-                layer_fused_h<3, false, kTrain>(pipe, X, Y, norm, mom);
-                norm = finish_moments<kTrain, HMoments>(mom, Y, small, g, xrow + ka.save.xhat[0],
-                                                        rstd_p + ka.save.rstd[0], ka.norm, eps, rs);
+                load_bias_n<NT>(small, g, Y);
+                layer_fused_h<3, false, kTrain, kOrderNormRelu, NT>(pipe, X, Y, norm, mom);
+                norm = finish_moments<kTrain, HMoments, NT>(mom, Y, small, g, xrow + ka.save.xhat[0],
+                                                            rstd_p + ka.save.rstd[0], ka.norm, eps, rs);
 #pragma unroll 1
                 for (int L = 1; L <= 3; L += 2) {
                     const float* small_a = small + L * kSmallPerLayerLds;
-                    load_bias16(small_a, g, X);
-                    layer_fused_h<8, true, kTrain>(pipe, Y, X, norm, mom);
-                    norm = finish_moments<kTrain, HMoments>(mom, X, small_a, g, xrow + ka.save.xhat[L],
-                                                            rstd_p + ka.save.rstd[L], ka.norm, eps, rs);
+                    load_bias_n<NT>(small_a, g, X);
+                    layer_fused_h<NT / 2, true, kTrain, kOrderNormRelu, NT>(pipe, Y, X, norm, mom);
+                    norm = finish_moments<kTrain, HMoments, NT>(mom, X, small_a, g, xrow + ka.save.xhat[L],
+                                                                rstd_p + ka.save.rstd[L], ka.norm, eps, rs);
                     const float* small_b = small_a + kSmallPerLayerLds;
-                    load_bias16(small_b, g, Y);
-                    layer_fused_h<8, true, kTrain>(pipe, X, Y, norm, mom);
-                    norm = finish_moments<kTrain, HMoments>(mom, Y, small_b, g, xrow + ka.save.xhat[L + 1],
-                                                            rstd_p + ka.save.rstd[L + 1], ka.norm, eps, rs);
+                    load_bias_n<NT>(small_b, g, Y);
+                    layer_fused_h<NT / 2, true, kTrain, kOrderNormRelu, NT>(pipe, X, Y, norm, mom);
+                    norm = finish_moments<kTrain, HMoments, NT>(mom, Y, small_b, g, xrow + ka.save.xhat[L + 1],
+                                                                rstd_p + ka.save.rstd[L + 1], ka.norm, eps, rs);
                 }
                 {
                     const f32x4* b = (const f32x4*)(small + 5 * kSmallPerLayerLds) + g * 4;
 #pragma unroll
                     for (int T = 0; T < 4; ++T) out[T] = b[T];
                 }
-                layer_out_h<kTrain>(pipe, Y, out, norm);
+                layer_out_h<kTrain, NT>(pipe, Y, out, norm);
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / rs);
                 if (!kTrain) {
@@ -674,7 +677,39 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
     const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     if (e >= kPackedFloats || (e >= kImageFloats && e < kWideFloats)) return;      // (the bounds block's four floats)
     float v = 0.f;
-    if (e >= kNarrowBwd8Offset) {
+    if (e >= kNarrowH8Offset) {
+        // split-precision forward image at 8 register tiles (nerf_layout.h): two f16 of one slab per float slot
+        if (pa.hidden > 128) return;
+        const int eb = e - kNarrowH8Offset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k;
+            const int tl = jj >> 2, r = jj & 3;
+            float w = 0.f;
+            if (stage < 3) {
+                w = pa.w0(16 * pair + row, 2 * stage + tl, kg, r);
+            } else if (stage < 3 + 16) {
+                const int L = 1 + (stage - 3) / 4, m = (stage - 3) % 4;
+                w = pa.wh(L, 16 * pair + row, 32 * m + 16 * tl + 4 * kg + r);
+            } else {
+                const int m = 2 * (stage - 19) + (pair >> 2), T = pair & 3;
+                w = pa.w5(16 * T + row, 32 * m + 16 * tl + 4 * kg + r);
+            }
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
+    } else if (e >= kNarrowBwd8Offset) {
         // transposed narrow image (nerf_layout.h): written for every network that can train at 8 register tiles
         if (pa.hidden > 128) return;
         const int eb = e - kNarrowBwd8Offset;
@@ -963,14 +998,20 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     static const Kernel narrow[2][2] = {
         {nerf_render_fwd_kernel<false, false, false, 8>, nerf_render_fwd_kernel<false, false, true, 8>},
         {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
+    static const Kernel narrow_half[2] = {nerf_render_fwd_kernel<false, true, false, 8>, nerf_render_fwd_kernel<false, true, true, 8>};
     static const Kernel narrow_train = nerf_render_fwd_kernel<true, false, false, 8>;
-    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_train = 0;
+    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_half[2] = {}, done_narrow_train = 0;
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
-    const int nt = train ? tt : tiles_for(shape_of(a).hidden);
-    const bool is_narrow = !half && nt < 16;
-    const Kernel kernel = is_narrow ? (train ? narrow_train : narrow[nt == 4][ps]) : kernels[train][half][ps];
-    unsigned* const done_mask = is_narrow ? (train ? &done_narrow_train : &done_narrow[nt == 4][ps]) : &done[train][half][ps];
+    // register tiles per sample of this launch: training 8 / 16 (train_tiles); inference 4 / 8 / 16 in fp32
+    // arithmetic, 8 / 16 in split-precision arithmetic
+    int nt = train ? tt : tiles_for(shape_of(a).hidden);
+    if (half && nt == 4) nt = 8;
+    const bool is_narrow = nt < 16;
+    const Kernel kernel = !is_narrow ? kernels[train][half][ps]
+                          : train ? narrow_train : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
+    unsigned* const done_mask = !is_narrow ? &done[train][half][ps]
+                                : train ? &done_narrow_train : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
     const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;

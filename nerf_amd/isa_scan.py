@@ -80,11 +80,13 @@ def scan(path):
     m0_write = -100
     vmem = []                   # vector-memory instructions in text order: (is LDS-DMA, inside asm)
     no_fallthrough = False      # the previous instruction was an unconditional branch
+    unknown_history = False     # the block was entered by a jump: operations older than `vmem` exist but were not seen
     for ln, raw in enumerate(open(path).read().splitlines(), 1):
         s = raw.strip()
         m = re.match(r"^(_Z\S+):", s)
         if m:
             kern = m.group(1)
+            unknown_history = False
         if s.startswith(";;#ASMSTART"):
             in_asm = True
             continue
@@ -94,8 +96,9 @@ def scan(path):
         label = re.match(r"^(\.?[A-Za-z_][\w.$]*):", s)
         if label:                # a label: other paths join here, keep the state (conservative) ...
             if no_fallthrough:   # ... unless the text above cannot fall into it (it ended in s_branch): the vector-memory
-                vmem = []        # history of whoever jumps here is not the text above (R6 then has nothing to count until
-                no_fallthrough = False        # the block has issued operations of its own)
+                vmem = []        # history of whoever jumps here is not the text above.  It is UNKNOWN, not empty: such a
+                unknown_history = True        # block is typically a rotated loop body whose real predecessor is its own
+                no_fallthrough = False        # latch, full of LDS-DMA issues — R6 assumes the worst for what it cannot see
             continue
         if not s or s.startswith((";", ".")):
             continue
@@ -110,7 +113,10 @@ def scan(path):
         if in_asm and op == "s_waitcnt":
             cnt = re.search(r"vmcnt\((\d+)\)", s)
             if cnt and int(cnt.group(1)) > 4:
-                young = vmem[-int(cnt.group(1)):]
+                n = int(cnt.group(1))
+                young = vmem[-n:]
+                if unknown_history and len(young) < n:       # what the block did not issue itself: assumed LDS-DMA pieces
+                    young = [(True, False)] * (n - len(young)) + young
                 if any(not dma for dma, _ in young) and sum(dma for dma, _ in young) > 4:
                     found.append((kern, ln, s, "R6", f"the {cnt.group(1)} youngest vector-memory ops hold "
                                   f"{sum(dma for dma, _ in young)} LDS-DMA pieces: the count is too high"))

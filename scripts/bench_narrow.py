@@ -1,4 +1,4 @@
-"""The headline 800x800x128 frame at hidden_size 256 / 128 / 64 (fp32 inference): kernel time, TFLOP/s on each network's
+"""The headline 800x800x128 frame at hidden_size 256 / 128 / 64 (inference, both arithmetics): kernel time, TFLOP/s on each network's
 own FLOP count and fraction of the fp32 MFMA peak.  python scripts/bench_narrow.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,9 +7,10 @@ from nerf_amd import NeRF, _lib
 dev = torch.device("cuda:0")
 cam_o, cam_r = bench.look_at(bench.CAMERA)
 cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
-for hidden, enc in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10)):
+for hidden, enc, prec in [(h, e, p) for p in ("fp32", "f16x3") for h, e in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10))]:
     torch.manual_seed(0)
     m = NeRF(focal_length=bench.FOCAL, hidden_size=hidden, encoding_size=enc).to(dev)
+    m.precision = prec
     flop = 2 * (3 * enc * hidden + 4 * hidden * hidden + 54 * hidden)
     with torch.no_grad():
         for _ in range(2):
@@ -21,5 +22,5 @@ for hidden, enc in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10)
         torch.cuda.synchronize()
         ms, n = _lib.timing_read(reset=True); _lib.timing(False)
     tf = 640000 * 127 * flop / (ms * 1e-3) / 1e12
-    print(f"hidden {hidden:3d} enc {enc:2d}: kernel {ms:8.2f} ms  {640000 * 128 / (ms * 1e-3):.3e} ray-samples/s  "
-          f"{tf:6.1f} TFLOP/s on {flop} FLOP/sample = {tf / 157.3:.3f} of the fp32 MFMA peak", flush=True)
+    print(f"{prec:5s} hidden {hidden:3d} enc {enc:2d}: kernel {ms:8.2f} ms  {640000 * 128 / (ms * 1e-3):.3e} ray-samples/s  "
+          f"{tf:6.1f} TFLOP/s on {flop} FLOP/sample = {tf / (157.3 if prec == 'fp32' else 2516.6):.3f} of the {'fp32' if prec == 'fp32' else 'f16 (x3 executed)'} MFMA peak", flush=True)

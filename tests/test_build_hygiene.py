@@ -75,6 +75,14 @@ def test_scanner_flags_an_overcounted_handover_wait(tmp_path):
     bad.write_text(body + wait % 7)                # one more: a piece of the opened stage may fly
     assert haz.scan(str(ok)) == []
     assert [h[3] for h in haz.scan(str(bad))] == ["R6"]
+    # a block entered only by a jump (a rotated loop body: its real predecessor is its own latch): the history above
+    # the label is not its history — R6 assumes LDS-DMA pieces for everything it cannot see
+    jumped = "_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n\ts_branch .LBB0_2\n.LBB0_1:\n" + stores
+    rot_ok, rot_bad = tmp_path / "rot_ok.s", tmp_path / "rot_bad.s"
+    rot_ok.write_text(jumped + wait % 5)           # its own store + at most 4 unseen pieces
+    rot_bad.write_text(jumped + wait % 7)          # 6 unseen operations may all be pieces of the opened stage
+    assert haz.scan(str(rot_ok)) == []
+    assert [h[3] for h in haz.scan(str(rot_bad))] == ["R6"]
     pure = tmp_path / "pure.s"                     # DMA-only waits (the weight gradient's ring) are by construction
     pure.write_text("_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n" + dma + dma + wait % 8)
     assert haz.scan(str(pure)) == []
