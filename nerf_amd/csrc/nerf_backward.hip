@@ -391,6 +391,163 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
     if (threadIdx.x < 8) ba.dymax[(int64_t)blockIdx.x * 8 + threadIdx.x] = __builtin_bit_cast(float, wmax[threadIdx.x]);
 }
 
+// The split-precision chain for a network that trains at 8 register tiles per sample (hidden_size <= 128): saved rows
+// 128 wide (a wave's 16-sample tile = 8 KiB), the transposed f16-pair image of nerf_layout.h: kNarrowBwdH8Offset
+// (2 stages for layer 5, 4 per hidden layer), 8 x_hat loads + 1 and 8 dY saves per layer in the hand-overs' counts.
+// Layer 0's gamma / beta partials take their turns at the end of the item (the two-stage layer-5 loop that opens the
+// next item has only two barriers), as in nerf_bwd_data_n8_kernel.
+constexpr int kYoungerL5N8 = 9, kYoungerHiddenN8 = 17;
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_n8_kernel(const BwdArgs ba) {
+    constexpr int NT = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NerfHipRenderArgs& a = ba.a;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* const ws = a.train_workspace;
+    float* const gb = (float*)(smem + kRingBytes + kSmallLdsBytes);
+    int* const wmax = (int*)(smem + kBwdLdsBytes);
+
+    {
+        stage_small_image(a.packed + kBlobFloats, (float*)(smem + kRingBytes));
+        for (int i = threadIdx.x; i < kGbFloats; i += 256) gb[i] = 0.f;
+        if (threadIdx.x < 8) wmax[threadIdx.x] = 0;
+    }
+    const float* small = (const float*)(smem + kRingBytes);
+
+    WeightPipe<kNarrowBwdH8Stages> pipe;
+    pipe.init(a.packed + kNarrowBwdH8Offset, smem, wave, lane);
+    pipe.issue();
+    pipe.issue();
+    __syncthreads();
+
+    float act[64];
+    f32x4 acc[16];
+    GammaBetaTurn turn;
+    turn.dst = gb + 16 * j + 4 * g;
+    turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    turn.wave = wave;
+
+    // one (padded ray, chunk) item per wave: dL/d(out) of every sample was written by
+    // nerf_composite_bwd_kernel (the suffix sum along the ray lives there), so the chunks of a ray
+    // are independent here and a small batch still fills the chip
+    // Addresses: a wave's 16-sample tile is wave-UNIFORM, so every saved row is (uniform 64-bit base of the tile, in
+    // SGPRs) + (this lane's constant 32-bit offset inside a tile) — no per-lane 64-bit pointer stays live across the
+    // loops.  That is not only two or three registers per pointer: a spilled pointer that the compiler reloads BEHIND
+    // a layer's burst of 16 saves + 16 loads gets a `s_waitcnt vmcnt(0)`, and vmcnt retires in order — the reload of
+    // an L1-resident scratch line then waits for the whole burst's HBM round trip (round 4: one such reload, for the
+    // 1/std address, cost this kernel a fifth of its time; scripts/vmcnt_drains.py finds them in the assembly).
+    // (lane_word: the same value behind an optimisation barrier, taken at every use — otherwise loop-invariant code
+    //  motion folds the offset into a per-lane 64-bit pointer again, and that pointer is what gets spilled)
+    auto lane_word = [](uint32_t v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    const uint32_t row_off = (uint32_t)tile_lane_word(j, g);           // floats, in a tile-major [16][256] tile
+    const uint32_t out_off = (uint32_t)(j * kOutPad + 4 * g);          // floats, in a [16][64] tile
+    for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c   (uniform)
+        {
+            const float* const ws_rows = ws + tile * (16 * 16 * NT);     // + L.xhat[l] / L.dy[l]: this tile's rows
+            const float* const ws_stat = ws + tile * 16;                 // + L.rstd[l]: this tile's 16 scalars
+            f32x4 dout[4];
+            {
+                const float* drow = ws + ba.L.dy5 + tile * (16 * kOutPad);
+                const uint32_t oo = lane_word(out_off);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + oo + T * 16);
+            }
+
+            f32x4 xh[16];
+            float rstd;
+            // x_hat / 1/std of layer 4 first: 17 loads that fly under the 4 stages of layer 5
+            {
+                const float* xrow = ws_rows + ba.L.xhat[4];
+                rstd = (ws_stat + ba.L.rstd[4])[lane_word(j)];
+                const uint32_t ro = lane_word(row_off);
+#pragma unroll
+                for (int T = 0; T < NT; ++T) xh[T] = *(const f32x4*)(xrow + ro + T * kTileT);
+            }
+            float unscale;
+            {
+                float m = 0.f;
+#pragma unroll
+                for (int T = 0; T < 4; ++T) m = abs_max4(m, dout[T]);
+                float amax;
+                const float sc = row_scale(m, unscale, amax);
+                note_max(wmax + 5, amax, lane);
+                h8 bh[2], bl[2];
+                split8(dout[0] * sc, dout[1] * sc, bh[0], bl[0]);
+                split8(dout[2] * sc, dout[3] * sc, bh[1], bl[1]);
+#pragma unroll
+                for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                layer_wide_h<2, kYoungerL5N8, NT>(pipe, acc, bh, bl, TurnHook{turn});
+            }
+#pragma unroll 1
+            for (int L = 4; L >= 0; --L) {
+                layer_norm_relu_bwd<true, NT>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
+                                          const_cast<float*>(ws_rows) + ba.L.dy[L] + lane_word(row_off), gb + L * 2 * kHidden,
+                                          turn, ba.inv_n, unscale);
+                if (L == 0) {
+                    // dy[0] feeds only the weight gradient, whose f16 pairs need ONE scale for the batch: a BOUND on
+                    // this sample's largest |dy_0| from the two scalars at hand, folded into the workgroup's maximum.
+                    // (The true maximum would take a pass over the 64 registers, and every place such a pass can go
+                    // makes the allocator spill 270-700 B inside the loops: 0.73 -> 1.05-1.29 ms.)
+                    //   |dz| <= |acc| unscale <= 2^21 C unscale   (B operands < 2^13, weights x 2^8, C = max column
+                    //                                               sum of |W_1|: the accumulator cannot exceed it)
+                    //   |dy| <= (|g dz| + |m1| + |x_hat| |m2|) / std <= 18 max|gamma| max|dz| / std
+                    //                                              (|m1|, |m2| <= max|g dz|; |x_hat| < 16)
+                    // K0 = 18 2^21 max|gamma_0| C with 1 % for rounding comes from the pack kernel.  The bound
+                    // overestimates by ~2^8: the batch's largest |dy_0| enters the weight gradient near 2^4 instead
+                    // of 2^12 — no overflow possible, elements down to 2^-7 of it keep all 22 bits, smaller ones
+                    // lose low bits that are below 2^-29 of the largest element.
+                    note_max(wmax + 0, rstd * unscale * a.packed[kBoundsOffset], lane);
+                    break;
+                }
+                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above (1/std first: its
+                // address is the one thing here that is not a row offset), all of them younger than the two stages
+                // this layer's loop opens first
+                {
+                    const float* xrow_n = ws_rows + ba.L.xhat[L - 1];
+                    rstd = (ws_stat + ba.L.rstd[L - 1])[lane_word(j)];
+                    const uint32_t ro = lane_word(row_off);
+#pragma unroll
+                    for (int T = 0; T < NT; ++T) xh[T] = *(const f32x4*)(xrow_n + ro + T * kTileT);
+                }
+                // the sample's largest |dy|: this layer's B-operand scale, and (folded into the
+                // workgroup's maximum) the weight-gradient kernel's
+                float m = 0.f;
+#pragma unroll
+                for (int T = 0; T < NT; ++T)
+                    m = abs_max4(m, f32x4{act[4 * T], act[4 * T + 1], act[4 * T + 2], act[4 * T + 3]});
+                float amax;
+                const float sc = row_scale(m, unscale, amax);
+                note_max(wmax + L, amax, lane);
+                h8 bh[NT / 2], bl[NT / 2];
+#pragma unroll
+                for (int mb = 0; mb < NT / 2; ++mb) {
+                    const int t0 = 8 * mb, t1 = 8 * mb + 4;
+                    split8(f32x4{act[t0], act[t0 + 1], act[t0 + 2], act[t0 + 3]} * sc,
+                           f32x4{act[t1], act[t1 + 1], act[t1 + 2], act[t1 + 3]} * sc, bh[mb], bl[mb]);
+                }
+#pragma unroll
+                for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                layer_wide_h<NT / 2, kYoungerHiddenN8, NT>(pipe, acc, bh, bl, TurnHook{turn});
+            }
+        }
+        for (int t = 0; t < kWavesPerWg; ++t) {   // layer 0's partials, in wave order
+            __syncthreads();
+            turn(t);
+        }
+        turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGbFloats; i += 256)
+        ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
+    if (threadIdx.x < 8) ba.dymax[(int64_t)blockIdx.x * 8 + threadIdx.x] = __builtin_bit_cast(float, wmax[threadIdx.x]);
+}
+
 // All six layers in ONE launch: job = blockIdx.x, heavy (hidden) layers first so that the short
 // layer-0 / layer-5 jobs fill the tail instead of running half-empty launches of their own.
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_kernel(const BwdArgs ba) {
@@ -453,6 +610,27 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) 
     } else {
         wgrad_body_ring<ShapeL5, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
                                              kSlabW5, kSlabB + 5 * kHidden, 5);
+    }
+}
+
+// ... at 8 register tiles per sample (f16-pair operands)
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_h_n8_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
+                      ba.data_grid, 8};
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kBlobFloats;
+    if (job < 4) {
+        wgrad_body_ring<ShapeHidN8, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * 128,
+                                                            ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * 128,
+                                                            small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
+                                                            kSlabB + (job + 1) * kHidden, job + 1);
+    } else if (job == 4) {
+        wgrad_body_ring<ShapeL0N8, kInputRaw, true>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB, 0);
+    } else {
+        wgrad_body_ring<ShapeL5N8, kInputAffineRelu, true>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                                           kSlabW5, kSlabB + 5 * kHidden, 5);
     }
 }
 
@@ -591,11 +769,13 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad_h);
     if (rc) return rc;
-    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0;
+    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0, done_data_h_n8 = 0, done_wgrad_h_n8 = 0;
     if (tt == 8) {
-        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n8_kernel, kBwdLdsBytes, device, &done_data_n8);
+        rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_h_n8_kernel, kBwdLdsBytes + 32, device, &done_data_h_n8)
+                  : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n8_kernel, kBwdLdsBytes, device, &done_data_n8);
         if (rc) return rc;
-        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n8);
+        rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_h_n8)
+                  : nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n8);
         if (rc) return rc;
     }
     int64_t grid = (int64_t)cus * 2;
@@ -608,12 +788,15 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     else
         hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
                            dim3(256), 0, st, ba);
-    if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
+    if (half && tt == 8) hipLaunchKernelGGL(nerf_bwd_data_h_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
+    else if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
     else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     const int wgrad_jobs = 6;
     const bool wgrad_half = half;
-    if (tt == 8)
+    if (tt == 8 && wgrad_half)
+        hipLaunchKernelGGL(nerf_wgrad_h_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+    else if (tt == 8)
         hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
     else if (wgrad_half)
         hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);

@@ -94,8 +94,7 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     };
     // beta / gamma gradients: sums over the 16 samples of a row, lane j keeps tile j.
     float kept[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    static_assert(NT == 16 || !kScaled, "the split-precision chain runs at full width");
-    if constexpr (kScaled) {
+    if constexpr (kScaled && NT == 16) {
         // split-precision chain (VALU-paced): a reduce-scatter butterfly (nerf_device.h: scatter_level8 / 4 /
         // take) applied as the tiles come: t, t + 8, t + 4, t + 12 — 2 DPP adds per value
 #pragma unroll
@@ -113,7 +112,8 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     } else {
         // fp32 chain (matrix-paced: its MFMAs take four times as long): one row_sum per value; the butterfly's
         // longer live ranges cost this kernel 120 B more spills than its shorter VALU phase gains
-        // (3.88 against 3.81 ms per 4096 x 64 step)
+        // (3.88 against 3.81 ms per 4096 x 64 step).  Also the narrow (NT = 8) split-precision chain: the butterfly
+        // is built for sixteen tiles.
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
             float v[8];

@@ -90,11 +90,11 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
     t.total = off;
     return t;
 }
-// register tiles per sample the TRAINING kernels of a launch run at: 8 for a narrow network in fp32 arithmetic
-// (hidden_size <= 128; <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator
-// tiles), else 16 (every network in split-precision arithmetic runs zero-padded in the full-width kernels)
+// register tiles per sample the TRAINING kernels of a launch run at: 8 for a narrow network (hidden_size <= 128;
+// <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator tiles), else 16
 __host__ __device__ inline int train_tiles(int hidden, int precision) {
-    return precision == NERF_HIP_PRECISION_FP32 && hidden <= 128 ? 8 : 16;
+    (void)precision;            // (both arithmetics have their narrow kernels)
+    return hidden <= 128 ? 8 : 16;
 }
 
 // Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the
@@ -435,10 +435,11 @@ constexpr int kSets = 4;       // 2: +2 % frame time; 3 and 5 defeat the unrolle
 // kEntryYounger: vector-memory operations the caller is KNOWN to have issued after the DMA of this
 // layer's stage 1 (saves of the LayerNorm backward, prefetches of the next x_hat tile): stages 0 and
 // 1 were issued before them, so their counted waits leave those operations in flight.
-template <int KB, int kEntryYounger, class Pipe, class Hook = NoHook>
+// NT = 8 (a network that trains at 8 register tiles): one half, kStages = KB.
+template <int KB, int kEntryYounger, int NT = 16, class Pipe, class Hook = NoHook>
 __device__ __forceinline__ void layer_wide_h(Pipe& pipe, f32x4 (&acc)[16], const h8 (&bhi)[KB],
                                              const h8 (&blo)[KB], Hook hook = Hook()) {
-    constexpr int kStages = 2 * KB, kUnits = 8 * kStages;
+    constexpr int kStages = (NT / 8) * KB, kUnits = 8 * kStages;
     h8 ah[kSets], al[kSets];
     __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
     const h8* st = (const h8*)pipe.template open_stage<kEntryYounger>();

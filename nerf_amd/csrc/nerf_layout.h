@@ -118,7 +118,13 @@ constexpr int kNarrowBwd8Offset = kNarrow4Offset + Narrow<4>::kFloats;
 // 4 for layers 1..4), pair i = out tile i; layer 5: stage s, pair i = (k block 2 s + (i >> 2), out tile i & 3), 2 stages
 constexpr int kNarrowH8Stages = 3 + 4 * 4 + 2;
 constexpr int kNarrowH8Offset = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFloats;
-constexpr int kPackedFloats = kNarrowH8Offset + kNarrowH8Stages * kStageFloats;
+// ... and its transposed counterpart for the split-precision data gradient at 8 register tiles: the slab format of
+// kBwdHBlobOffset with ONE half (pair i = in tile i): layer 5 = 2 stages (k blocks m = 0, 1 of the 64 padded outputs),
+// layers 4, 3, 2, 1 = 4 stages each (k block m of the 128 out features);
+// element (lane (row, kg), jj) = 2^kWScaleLog2 * W[32 m + 16 (jj >> 2) + 4 kg + (jj & 3)][16 i + row]
+constexpr int kNarrowBwdH8Stages = 2 + 4 * 4;
+constexpr int kNarrowBwdH8Offset = kNarrowH8Offset + kNarrowH8Stages * kStageFloats;
+constexpr int kPackedFloats = kNarrowBwdH8Offset + kNarrowBwdH8Stages * kStageFloats;
 static_assert(kWideFloats % 4 == 0, "narrow images start 16-byte aligned");
 // register tiles a network of `hidden` features needs, rounded up to an instantiated width
 __host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16); }

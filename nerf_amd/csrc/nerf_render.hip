@@ -352,7 +352,6 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     static_assert(NT != 4 || (!kTrain && !kHalf), "4 register tiles: fp32 inference only (training and the "
                                                   "split-precision arithmetic run at 8 or 16)");
-    static_assert(NT == 16 || !(kTrain && kHalf), "split-precision training runs at full width (nerf_device.h: train_tiles)");
     typedef Narrow<NT> N;
     typedef WeightPipe<N::kStages> Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -677,7 +676,31 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
     const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     if (e >= kPackedFloats || (e >= kImageFloats && e < kWideFloats)) return;      // (the bounds block's four floats)
     float v = 0.f;
-    if (e >= kNarrowH8Offset) {
+    if (e >= kNarrowBwdH8Offset) {
+        // transposed split-precision image at 8 register tiles (nerf_layout.h)
+        if (pa.hidden > 128) return;
+        const int eb = e - kNarrowBwdH8Offset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int slab = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, word = in_stage & 3;
+        const int row = lane & 15, kg = lane >> 4;
+        const int pair = slab >> 1;
+        const bool is_lo = (slab & 1) != 0;
+        _Float16 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jj = 2 * word + k;
+            const int m = stage < 2 ? stage : (stage - 2) % 4;
+            const int out = 32 * m + 16 * (jj >> 2) + 4 * kg + (jj & 3);
+            float w = stage < 2 ? pa.w5(out, 16 * pair + row) : pa.wh(4 - (stage - 2) / 4, out, 16 * pair + row);
+            w = __builtin_fminf(__builtin_fmaxf(w * (float)(1 << kWScaleLog2), -65504.f), 65504.f);
+            const _Float16 hi = (_Float16)w;
+            h[k] = is_lo ? (_Float16)(w - (float)hi) : hi;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        v = __builtin_bit_cast(float, h2v{h[0], h[1]});
+    } else if (e >= kNarrowH8Offset) {
         // split-precision forward image at 8 register tiles (nerf_layout.h): two f16 of one slab per float slot
         if (pa.hidden > 128) return;
         const int eb = e - kNarrowH8Offset;
@@ -999,8 +1022,8 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
         {nerf_render_fwd_kernel<false, false, false, 8>, nerf_render_fwd_kernel<false, false, true, 8>},
         {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
     static const Kernel narrow_half[2] = {nerf_render_fwd_kernel<false, true, false, 8>, nerf_render_fwd_kernel<false, true, true, 8>};
-    static const Kernel narrow_train = nerf_render_fwd_kernel<true, false, false, 8>;
-    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_half[2] = {}, done_narrow_train = 0;
+    static const Kernel narrow_train[2] = {nerf_render_fwd_kernel<true, false, false, 8>, nerf_render_fwd_kernel<true, true, false, 8>};
+    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_half[2] = {}, done_narrow_train[2] = {};
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
     // register tiles per sample of this launch: training 8 / 16 (train_tiles); inference 4 / 8 / 16 in fp32
@@ -1009,9 +1032,9 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (half && nt == 4) nt = 8;
     const bool is_narrow = nt < 16;
     const Kernel kernel = !is_narrow ? kernels[train][half][ps]
-                          : train ? narrow_train : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
+                          : train ? narrow_train[half] : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
     unsigned* const done_mask = !is_narrow ? &done[train][half][ps]
-                                : train ? &done_narrow_train : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
+                                : train ? &done_narrow_train[half] : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
     const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;

@@ -1,14 +1,14 @@
 #!/bin/bash
-# usage: scripts/pmc_train.sh TAG [fp32|f16x3] [main|legacy]   (GPU box)
+# usage: scripts/pmc_train.sh TAG [fp32|f16x3] [main|legacy] [hidden_size encoding_size]   (GPU box)
 # rocprofv3 of one training step (scripts/bench_train.py, or bench_train_legacy.py for the 8 x 256 network of
 # examples/nerf.pth; 4096 rays x 64, arithmetic as given):
 # one --kernel-trace --stats run, then one --pmc pass per counter group (never combined with a trace),
 # summarised per dispatch for the three MFMA kernels of the step into gpurun_out/TAG_{fwd,dgrad,wgrad}_pmc.json.
 set -e
-TAG=$1; PREC=${2:-fp32}; NET=${3:-main}
+TAG=$1; PREC=${2:-fp32}; NET=${3:-main}; HID=${4:-256}; ENC=${5:-32}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-B="python3 $PWD/scripts/bench_train.py 4096 $PREC"
+B="python3 $PWD/scripts/bench_train.py 4096 $PREC $HID $ENC"
 FWD="nerf_render_fwd_kernel<true"; DG=nerf_bwd_data_; WG=nerf_wgrad_
 if [ "$NET" = legacy ]; then
   B="python3 $PWD/scripts/bench_train_legacy.py 4096 64 $PREC"
