@@ -13,10 +13,13 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("hidden", [256, 128])
 @pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
-def test_forty_steps_track_the_cpu_reference_port(train_precision):
+def test_forty_steps_track_the_cpu_reference_port(train_precision, hidden):
     """Both training arithmetics (fp32 MFMA; f16 pairs in forward, data and weight gradient) against the
-    SAME CPU run of the reference's ops: same bounds."""
+    SAME CPU run of the reference's ops: same bounds.  hidden 128: the same recipe on a narrow network
+    (`NeRF(hidden_size=128)`, nerf/model.py:471-475), i.e. through the kernels instantiated at 8 register
+    tiles per sample — training forward, data gradient, weight gradient and the inference render."""
     from nerf_amd import NeRF
     from nerf_amd import trainer as T
     dev = torch.device("cuda:0")
@@ -25,10 +28,10 @@ def test_forty_steps_track_the_cpu_reference_port(train_precision):
     data = T.PixelRayDataset(images[:-1], torch.zeros(5, 16, 16, dtype=torch.int64, device=dev),
                              poses[:-1], focal)
     gen = torch.Generator().manual_seed(5)
-    cfg = dict(O.default_config(), focal_length=focal)
+    cfg = dict(O.default_config(), focal_length=focal, hidden_size=hidden)
 
-    params0 = golden_params(1.0)
-    model = NeRF(focal_length=focal)
+    params0 = golden_params(1.0) if hidden == 256 else O.init_params(seed=0, cfg=cfg)
+    model = NeRF(focal_length=focal, hidden_size=hidden)
     model.load_state_dict(params0)
     model = model.to(dev)
     model.train_precision = train_precision
@@ -70,7 +73,7 @@ def test_forty_steps_track_the_cpu_reference_port(train_precision):
                                        cam_r.cpu(), 16, 16, focal, S)
     truth = images[-1:].cpu()
     psnr_gpu, psnr_cpu = float(O.psnr(render.cpu(), truth)), float(O.psnr(ref_render, truth))
-    print(f"[{train_precision}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port {psnr_cpu:.4f} dB; "
+    print(f"[{train_precision}, hidden {hidden}] held-out PSNR after {steps} steps: HIP {psnr_gpu:.4f} dB, CPU port {psnr_cpu:.4f} dB; "
           f"max loss deviation {float((gl - cl).abs().max()):.2e}")
     assert abs(psnr_gpu - psnr_cpu) <= 0.01
 
