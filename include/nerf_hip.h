@@ -37,9 +37,13 @@ extern "C" {
  * hidden_size H in [1, 256], encoding_size in {2, 4, .. 32} (inputs of the first Linear = 3 * encoding_size in
  * {6, 12, .. 96}: nerf/model.py:526, :550-551) and the rows of the last Linear, 1 density + 3 color +
  * segmentation_outputs (nerf/model.py:541-542, :591-592) in [4, 64], are RUN-TIME arguments of pack / forward /
- * backward.  The kernels compute at the compiled-in maxima below; a narrower network runs zero-padded inside
- * them, which is exact (LayerNorm divides by H; nerf_amd/csrc/nerf_layout.h has the argument) and costs what the
- * full-width network costs.  color_outputs other than 3 is not supported.  256 / 96 / 54 for the defaults. */
+ * backward.  The kernels exist at three widths — 16, 8 and 4 register tiles of 16 features per sample — and a
+ * launch runs at the smallest one that holds H: inference at 4 / 8 / 16 tiles in FP32 arithmetic and 8 / 16 in
+ * F16X3, training (forward with saves, data gradient, weight gradient) at 8 / 16 in both; a network of H <= 128
+ * therefore costs what a 128-wide one costs, not what the 256-wide one does.  Inside the chosen width (and for
+ * encoding_size / num_outputs below the maxima) a network runs zero-padded, which is exact (LayerNorm divides by
+ * H; nerf_amd/csrc/nerf_layout.h has the argument).  color_outputs other than 3 is not supported.  256 / 96 / 54
+ * for the defaults. */
 #define NERF_HIP_HIDDEN 256
 #define NERF_HIP_ENC_INPUTS 96
 #define NERF_HIP_DEFAULT_OUTPUTS 54

@@ -253,9 +253,10 @@ class NeRF(nn.Module):
 
     def _check_shape(self):
         """hidden_size (<= 256), encoding_size (even, <= 32) and the number of segmentation classes (<= 60) are
-        run-time arguments of the kernels: a network narrower than the compiled-in 256 / 96 / 64 runs zero-padded
-        inside them, which is exact (nerf_amd/csrc/nerf_layout.h: Shape) and costs what the full width costs.
-        Three color channels are compiled in (the reference's scripts never use another count)."""
+        run-time arguments of the kernels, which exist at 16 / 8 / 4 register tiles per sample: a launch runs at the
+        smallest width that holds hidden_size (a narrow network at its own cost) and zero-padded inside it, which is
+        exact (nerf_amd/csrc/nerf_layout.h: Shape, Narrow).  Three color channels are compiled in (the reference's
+        scripts never use another count)."""
         if self.color_outputs != 3 or not 1 <= self.hidden_size <= 256 or self.encoding_size % 2 != 0 or \
                 not 2 <= self.encoding_size <= 32 or not 0 <= self.segmentation_outputs <= 60:
             raise NotImplementedError(

@@ -1,5 +1,5 @@
 """The headline 800x800x128 frame at hidden_size 256 / 128 / 64 (inference, both arithmetics): kernel time, TFLOP/s on each network's
-own FLOP count and fraction of the fp32 MFMA peak.  python scripts/bench_narrow.py"""
+own FLOP count and fraction of the fp32 MFMA peak.  python scripts/bench_narrow.py [hidden_size encoding_size fp32|f16x3]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -7,7 +7,10 @@ from nerf_amd import NeRF, _lib
 dev = torch.device("cuda:0")
 cam_o, cam_r = bench.look_at(bench.CAMERA)
 cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
-for hidden, enc, prec in [(h, e, p) for p in ("fp32", "f16x3") for h, e in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10))]:
+configs = [(h, e, p) for p in ("fp32", "f16x3") for h, e in ((256, 32), (128, 32), (96, 32), (64, 32), (64, 16), (40, 10))]
+if len(sys.argv) > 3:                      # one configuration (under the profiler): hidden_size encoding_size precision
+    configs = [(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])]
+for hidden, enc, prec in configs:
     torch.manual_seed(0)
     m = NeRF(focal_length=bench.FOCAL, hidden_size=hidden, encoding_size=enc).to(dev)
     m.precision = prec
