@@ -136,7 +136,11 @@ constexpr NormDivisor kFullWidth = {1.0f / 256.0f};
 // ---------------------------------------------------------------------------------------------
 // weight stream: global -> LDS by LDS-DMA, two stages ahead of the MFMAs
 // ---------------------------------------------------------------------------------------------
-template <int kStagesInImage>
+// kDepth: ring slots.  3 (every full-width kernel): the DMA of stage s + 2 is issued when stage s opens, the hand-over
+// of stage s leaves its 4 pieces in flight.  2 (the narrow inference kernels, which then fit THREE workgroups of 48 KiB
+// on a CU): the DMA of stage s + 1 is issued when stage s opens and has that stage's MFMAs to land — nothing of it may
+// still fly at the next hand-over (vmcnt(0 + younger)).
+template <int kStagesInImage, int kDepth = 3>
 struct WeightPipe {
     const char* blob;           // packed image, stage 0
     char* ring;                 // LDS ring base
@@ -192,7 +196,7 @@ struct WeightPipe {
                 : "memory");
         }
         issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;
-        issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
+        issue_slot = (issue_slot + 1 == kDepth) ? 0 : issue_slot + 1;
     }
 
     // Top of a stage: this wave's DMA pieces of the stage have landed (the 4 youngest = the next
@@ -213,11 +217,12 @@ struct WeightPipe {
     template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
         static_assert(kYounger >= 0 && 4 + kYounger <= 63, "vmcnt immediate");
-        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"(4 + kYounger) : "memory");
+        static_assert(kDepth == 3 || kDepth == 2, "ring depth");
+        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"((kDepth == 3 ? 4 : 0) + kYounger) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;
-        read_slot = (read_slot + 1 == kRing) ? 0 : read_slot + 1;
+        read_slot = (read_slot + 1 == kDepth) ? 0 : read_slot + 1;
         return p;
     }
     __device__ __forceinline__ void prefetch_next() {

@@ -347,13 +347,24 @@ __device__ __forceinline__ void layer_out_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (
 // kPerSample: the instantiation that also writes the optional per-sample outputs (NeRF.forward's
 // tensors, compositing weights for the hierarchical resampler, debug outputs); the render-only
 // instantiations carry none of that code or its registers.
+// Narrow inference kernels (NT < 16, render-only): a TWO-slot weight ring (48.25 KiB of LDS) and <= 168 registers, so
+// that THREE workgroups share a CU — with a third of the MFMA work per chunk, the per-sample VALU phases (encoding,
+// LayerNorm finishing, compositing) need a second partner to hide under.
+template <bool kTrain, bool kPerSample, int NT>
+constexpr bool three_per_cu() { return NT < 16 && !kTrain && !kPerSample; }
+
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
-__global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArgs ka) {
+__global__ __launch_bounds__(256, (three_per_cu<kTrain, kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     static_assert(NT != 4 || (!kTrain && !kHalf), "4 register tiles: fp32 inference only (training and the "
                                                   "split-precision arithmetic run at 8 or 16)");
     typedef Narrow<NT> N;
-    typedef WeightPipe<N::kStages> Pipe;
+    constexpr int kDepth = three_per_cu<kTrain, kPerSample, NT>() ? 2 : 3;
+    constexpr int kRingB = kDepth * kStageBytes, kLdsB = kRingB + kSmallLdsBytes;
+    // (the split-precision kernel's LDS stash of per-lane state exists for the 256-register full-width kernel; at
+    //  8 register tiles the state stays in registers)
+    constexpr bool kStash = kHalf && !kTrain && kDepth == 3;
+    typedef WeightPipe<(kHalf && NT == 8 ? kNarrowH8Stages : N::kStages), kDepth> Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -364,15 +375,15 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
 
     // small image -> LDS (once per workgroup)
     {
-        stage_small_image(a.packed + (kHalf ? kHSmallOffset : kBlobFloats), (float*)(smem + kRingBytes));
+        stage_small_image(a.packed + (kHalf ? kHSmallOffset : kBlobFloats), (float*)(smem + kRingB));
     }
-    const float* small = (const float*)(smem + kRingBytes);
+    const float* small = (const float*)(smem + kRingB);
 
     Pipe pipe;
     pipe.init(a.packed + (kHalf ? (NT == 16 ? kHBlobOffset : kNarrowH8Offset)
                                 : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
     pipe.issue();
-    pipe.issue();
+    if (kDepth == 3) pipe.issue();
     __syncthreads();          // small image visible (this also drains the two DMA stages once)
 
     f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators (the first NT of them)
@@ -391,14 +402,14 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
         Ray ray = load_ray(a, local);
         RayAccum racc;
         racc.reset();
-        float* const stash = (float*)(smem + kLdsBytes) + (wave * 64 + lane) * kStashFloatsPerLane;
-        float* const ray_stash = (float*)(smem + kLdsBytes + kStashBytes) + wave * 8;
-        if (kHalf && !kTrain && lane == 0) {     // (a training item is one chunk: nothing to park)
+        float* const stash = (float*)(smem + kLdsB) + (wave * 64 + lane) * kStashFloatsPerLane;
+        float* const ray_stash = (float*)(smem + kLdsB + kStashBytes) + wave * 8;
+        if (kStash && lane == 0) {     // (a training item is one chunk: nothing to park)
             *(f32x4*)ray_stash = f32x4{ray.o[0], ray.o[1], ray.o[2], ray.d[0]};
             ray_stash[4] = ray.d[1];
             ray_stash[5] = ray.d[2];
         }
-        if (kHalf && !kTrain) asm volatile("" ::: "memory");    // the reads of the stash below stay below
+        if (kStash) asm volatile("" ::: "memory");    // the reads of the stash below stay below
 
         const int c_begin = kTrain ? (int)(unit - slot * chunks) : 0;
         const int c_end = kTrain ? c_begin + 1 : chunks;
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
             const bool ok = s < P;
             const int64_t tile = slot * chunks + c;         // chunk index in the workspace
             const int64_t sp = tile * 16 + j;               // padded sample index
-            if (kHalf && !kTrain) {                         // the wave's ray, back from LDS (broadcast)
+            if (kStash) {                         // the wave's ray, back from LDS (broadcast)
                 const f32x4 r0 = *(const f32x4*)ray_stash;
                 ray.o[0] = r0.x, ray.o[1] = r0.y, ray.o[2] = r0.z, ray.d[0] = r0.w;
                 ray.d[1] = ray_stash[4], ray.d[2] = ray_stash[5];
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                                   (float)(1 << (kWScaleLog2 + kXScaleLog2));
                 // x_hat is scale-free; the saved 1/std is the one of the unscaled activations
                 const float rs = (float)(1 << (kWScaleLog2 + kXScaleLog2));
-                if (!kTrain) {
+                if (kStash) {
                     *(f32x4*)stash = f32x4{racc.carry, racc.rgb0, racc.rgb1, racc.rgb2};
                     *(f32x4*)(stash + 4) = f32x4{racc.seg_m, racc.seg_s, dist, 0.f};
                 }
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void nerf_render_fwd_kernel(const KernelArg
                 layer_out_h<kTrain, NT>(pipe, Y, out, norm);
 #pragma unroll
                 for (int T = 0; T < 4; ++T) out[T] = out[T] * (1.0f / rs);
-                if (!kTrain) {
+                if (kStash) {
                     const f32x4 s0 = *(const f32x4*)stash, s1 = *(const f32x4*)(stash + 4);
                     racc.carry = s0.x, racc.rgb0 = s0.y, racc.rgb1 = s0.z, racc.rgb2 = s0.w;
                     racc.seg_m = s1.x, racc.seg_s = s1.y, dist = s1.z;
@@ -1035,10 +1046,13 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
                           : train ? narrow_train[half] : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
     unsigned* const done_mask = !is_narrow ? &done[train][half][ps]
                                 : train ? &done_narrow_train[half] : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
-    const int lds_bytes = half ? kLdsBytesHalf : kLdsBytes;
+    // LDS: three-slot ring + small image (+ the split-precision kernel's stash); the render-only narrow kernels run a
+    // two-slot ring without a stash, three workgroups per CU
+    const bool three = is_narrow && !train && !ps;
+    const int lds_bytes = three ? 2 * kStageBytes + kSmallLdsBytes : (half ? kLdsBytesHalf : kLdsBytes);
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;
-    int64_t grid = (int64_t)cus * 2;              // 2 workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs)
+    int64_t grid = (int64_t)cus * (three ? 3 : 2);   // workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs; narrow: 48.25 KiB, <= 168)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
