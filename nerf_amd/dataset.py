@@ -1,5 +1,5 @@
-"""Mirror of ``nerf.dataset.PixelRayDataset`` (nerf/dataset.py:175-316) with an on-device batched
-sampler.
+"""Mirrors of ``nerf.dataset.PixelRayDataset`` (nerf/dataset.py:175-316), with an on-device batched
+sampler, and of ``nerf.dataset.ImageRayDataset`` (nerf/dataset.py:6-172).
 
 ``dataset[idx]`` keeps the reference's per-example dictionary (same keys, shapes and the
 ``pose_d`` quirk) as plain torch indexing, so it still plugs into a ``DataLoader``.  The fast path
@@ -122,3 +122,50 @@ class PixelRayDataset(data.Dataset):
             batch = self.gather(idx)
             batch["global_n"] = global_n
             yield batch
+
+
+class ImageRayDataset(data.Dataset):
+    """Block-stratified ray batches (nerf/dataset.py:6-172): every example is ``num_samples_per_block`` rays from
+    EACH cell of a ``num_vertical_blocks`` x ``num_horizontal_blocks`` grid over one image — [samples, blocks]
+    rays with their pixels, poses and states.  No script or notebook of the reference uses it; it is mirrored so
+    that a caller of the reference's data module finds both classes.  Same constructor, length, keys, shapes and
+    dtypes; the in-cell picks are ONE ``torch.multinomial`` over uniform weights on the CPU generator, exactly
+    where the reference draws them (:134-137), so a seeded run picks the same rays (fixture G10).  Kept quirk: the
+    image is ``idx // cell_area`` while the length is ``images * cell_area // samples`` (:96-97, :156-158), so only
+    the first ``images / samples`` images are ever visited."""
+
+    def __init__(self, images, poses, states, focal_length, num_vertical_blocks=8, num_horizontal_blocks=8,
+                 num_samples_per_block=2):
+        self.images, self.poses, self.states = images, poses, states
+        self.num_vertical_blocks = num_vertical_blocks
+        self.num_horizontal_blocks = num_horizontal_blocks
+        self.num_samples_per_block = num_samples_per_block
+        height, width = images.shape[1], images.shape[2]
+        self.rays = NeRF.generate_rays(height, width, focal_length, dtype=images.dtype, device=images.device)
+        self.vertical_block_size = height // num_vertical_blocks
+        self.horizontal_block_size = width // num_horizontal_blocks
+        self.total_block_area = self.vertical_block_size * self.horizontal_block_size
+        # top-left pixel of every grid cell, cells in row-major order: [1, cells]
+        cell = torch.arange(num_vertical_blocks * num_horizontal_blocks, device=images.device).unsqueeze(0)
+        self._cell_row0 = (cell // num_horizontal_blocks) * self.vertical_block_size
+        self._cell_col0 = (cell % num_horizontal_blocks) * self.horizontal_block_size
+
+    def __len__(self):
+        return (self.images.shape[0] * self.total_block_area) // self.num_samples_per_block
+
+    def __getitem__(self, idx):
+        dev = self.images.device
+        cells = self.num_vertical_blocks * self.num_horizontal_blocks
+        # position inside the cell, one per (sample, cell): uniform with replacement (the reference's draw)
+        pick = torch.multinomial(torch.ones(self.num_samples_per_block, self.total_block_area), cells,
+                                 replacement=True).to(dev)
+        image_hi = pick // self.horizontal_block_size + self._cell_row0
+        image_wi = pick % self.horizontal_block_size + self._cell_col0
+        image_bi = torch.full(image_hi.shape, idx // self.total_block_area, dtype=torch.int64, device=dev)
+        pose = self.poses[image_bi]
+        rays = self.rays[image_hi, image_wi]
+        pose_o, pose_d = pose[..., :3, 3], pose[..., :3, :3]
+        rays_o, rays_d = NeRF.rays_to_world_coordinates(rays, pose_o, pose_d)
+        return dict(image_bi=image_bi, image_hi=image_hi, image_wi=image_wi,
+                    pixels=self.images[image_bi, image_hi, image_wi], states=self.states[image_bi], rays=rays,
+                    pose_o=pose_o, pose_d=pose_d, rays_o=rays_o, rays_d=rays_d)

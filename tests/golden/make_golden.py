@@ -6,7 +6,7 @@ Run in the build container only (the reference never travels to the GPU box):
 
 It imports ``nerf.model`` / ``nerf.dataset`` from /root/reference (read-only, not copied),
 evaluates generation C of the renderer on seeded inputs and stores inputs + outputs as
-small ``.npz`` files.  Fixture ids follow SURVEY.md section 8c (G1..G8).  Everything is
+small ``.npz`` files.  Fixture ids follow SURVEY.md section 8c (G1..G8; G10: ImageRayDataset).  Everything is
 fp32; default init under ``torch.manual_seed(0)``; weights are stored once in
 ``params_seed0.npz`` and the "x3" variants multiply the six Linear weight matrices by 3.
 Each render fixture also stores the last-interval density of every ray so tests can mask
@@ -26,7 +26,7 @@ sys.path.insert(0, REFERENCE)
 warnings.filterwarnings("ignore")
 
 from nerf.model import NeRF            # noqa: E402  (the reference)
-from nerf.dataset import PixelRayDataset  # noqa: E402
+from nerf.dataset import PixelRayDataset, ImageRayDataset  # noqa: E402
 
 LINEAR_SLOTS = (0, 3, 6, 9, 12, 15)
 
@@ -203,6 +203,25 @@ def main():
          **{k: torch.stack([it[k] for it in items]) for k in
             ("image_wi", "image_hi", "image_bi", "pixels", "label", "rays", "pose_o", "pose_d",
              "rays_o", "rays_d")})
+
+    # ---- G10: ImageRayDataset (nerf/dataset.py:6-172): block-stratified batches, seeded CPU draws ---------
+    torch.manual_seed(11)
+    images = torch.rand(4, 12, 10, 3)
+    states = torch.randn(4, 5)
+    poses = torch.eye(4).repeat(4, 1, 1)
+    for b in range(4):
+        poses[b, :3, :3] = rot[b % 3]
+        poses[b, :3, 3] = eye[b % 3] * (1.5 + b)
+    ds = ImageRayDataset(images, poses, states, 112.0, num_vertical_blocks=3, num_horizontal_blocks=2,
+                         num_samples_per_block=2)
+    picks = [0, 7, 19, 20, 39]
+    torch.manual_seed(12)                      # the draws of the five items, in this order
+    items = [ds[i] for i in picks]
+    save("g10_image_dataset", images=images, states=states, poses=poses, picks=picks, length=len(ds),
+         **{k: torch.stack([it[k] for it in items]) for k in
+            ("image_bi", "image_hi", "image_wi", "pixels", "states_out", "rays", "pose_o", "pose_d", "rays_o", "rays_d")
+            if k != "states_out"},
+         states_out=torch.stack([it["states"] for it in items]))
 
 
 if __name__ == "__main__":
