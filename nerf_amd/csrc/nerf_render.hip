@@ -351,7 +351,7 @@ __device__ __forceinline__ void layer_out_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (
 // that THREE workgroups share a CU — with a third of the MFMA work per chunk, the per-sample VALU phases (encoding,
 // LayerNorm finishing, compositing) need a second partner to hide under.
 template <bool kTrain, bool kPerSample, int NT>
-constexpr bool three_per_cu() { return NT < 16 && !kTrain && !kPerSample; }
+constexpr bool three_per_cu() { return NT < 16 && !kPerSample; }
 
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
 __global__ __launch_bounds__(256, (three_per_cu<kTrain, kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
@@ -1048,7 +1048,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
                                 : train ? &done_narrow_train[half] : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
     // LDS: three-slot ring + small image (+ the split-precision kernel's stash); the render-only narrow kernels run a
     // two-slot ring without a stash, three workgroups per CU
-    const bool three = is_narrow && !train && !ps;
+    const bool three = is_narrow && !ps;
     const int lds_bytes = three ? 2 * kStageBytes + kSmallLdsBytes : (half ? kLdsBytesHalf : kLdsBytes);
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;
