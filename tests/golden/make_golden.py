@@ -6,7 +6,7 @@ Run in the build container only (the reference never travels to the GPU box):
 
 It imports ``nerf.model`` / ``nerf.dataset`` from /root/reference (read-only, not copied),
 evaluates generation C of the renderer on seeded inputs and stores inputs + outputs as
-small ``.npz`` files.  Fixture ids follow SURVEY.md section 8c (G1..G8; G10: ImageRayDataset).  Everything is
+small ``.npz`` files.  Fixture ids follow SURVEY.md section 8c (G1..G8; G10: ImageRayDataset; G11: narrow networks).  Everything is
 fp32; default init under ``torch.manual_seed(0)``; weights are stored once in
 ``params_seed0.npz`` and the "x3" variants multiply the six Linear weight matrices by 3.
 Each render fixture also stores the last-interval density of every ray so tests can mask
@@ -222,6 +222,33 @@ def main():
             ("image_bi", "image_hi", "image_wi", "pixels", "states_out", "rays", "pose_o", "pose_d", "rays_o", "rays_d")
             if k != "states_out"},
          states_out=torch.stack([it["states"] for it in items]))
+
+    # ---- G11: NARROW networks (constructor keywords of nerf/model.py:471-475): render + one training gradient ----
+    # hidden_size 128 / encoding 32 / 50 classes, hidden 64 / encoding 16 / 7 classes, hidden 40 / encoding 10 / 3 classes
+    # — what the kernels instantiated at 8 and 4 register tiles per sample are held to (weights x 2: sharper fields)
+    for tag, kw in (("h128", dict(hidden_size=128)), ("h64", dict(hidden_size=64, encoding_size=16, segmentation_outputs=7)),
+                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3))):
+        torch.manual_seed(21)
+        m = NeRF(**kw)
+        with torch.no_grad():
+            for slot in LINEAR_SLOTS:
+                m.prediction_heads[slot].weight.mul_(2.0)
+        st = stages(m, rays_o, rays_d, 48)
+        torch.manual_seed(22)
+        u = torch.rand(64, 32)
+        noise = torch.randn(64, 31, 1)
+        target = torch.rand(64, 3)
+        # the reference's render_rays draws rand [N,S] then randn [N,S-1,1] (model.py:432, :652): replay them
+        torch.manual_seed(22)
+        pix, _ = m.render_rays(rays_o, rays_d, 32, randomly_sample=True, density_noise_std=0.5)
+        loss = ((pix - target.unsqueeze(1)) ** 2).mean()
+        m.zero_grad()
+        loss.backward()
+        save("g11_narrow_" + tag, rays_o=rays_o, rays_d=rays_d, u=u, noise=noise, noise_std=0.5, target=target,
+             loss=loss.detach(), rgb=st["rgb"], seg_out=st["seg_out"], density=st["density"], color=st["color"],
+             last_density=st["last_density"],
+             **{"param." + k: v for k, v in m.state_dict().items()},
+             **{"grad." + k: p.grad for k, p in m.named_parameters()})
 
 
 if __name__ == "__main__":

@@ -193,6 +193,49 @@ def test_layer_norm_with_a_large_common_bias(shape, precision):
         assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("tag,kw", [("h128", dict(hidden_size=128)),
+                                    ("h64", dict(hidden_size=64, encoding_size=16, segmentation_outputs=7)),
+                                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3))])
+def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
+    """Fixture G11 — the REFERENCE's own narrow networks (tests/golden/make_golden.py ran `nerf.model.NeRF(**kw)`): the
+    kernels instantiated at 8 / 4 register tiles per sample against the reference's render, per-sample field, training
+    loss and 22 gradients on the same rays and captured draws, not only against the oracle."""
+    from conftest import load_golden, stable_rays
+    from nerf_amd import NeRF
+    dev = torch.device("cuda:0")
+    g = load_golden("g11_narrow_" + tag)
+    params = {k[6:]: v for k, v in g.items() if k.startswith("param.")}
+    model = NeRF(**kw)
+    model.load_state_dict(params)
+    model = model.to(dev)
+    model.precision = model.train_precision = precision
+    o, d = g["rays_o"].to(dev), g["rays_d"].to(dev)
+    with torch.no_grad():
+        rgb, seg = model.render_rays(o, d, 48)
+        t = model.sample_along_rays(o, d, 48, randomly_sample=False)
+        _, dens, col, _ = model(o, d, t.contiguous())
+    ok = stable_rays(g["last_density"])
+    assert (rgb[:, 0].cpu() - g["rgb"])[ok].abs().max() <= 1e-5                 # (BASELINE bar: 1e-4)
+    assert (seg[:, 0].cpu() - g["seg_out"])[ok].abs().max() <= 1e-4
+    assert (dens.cpu() - g["density"]).abs().max() <= 2e-5 * max(1.0, float(g["density"].abs().max()))
+    assert (col.cpu() - g["color"]).abs().max() <= 2e-5 * max(1.0, float(g["color"].abs().max()))
+    pixels, _ = model.render_rays(o, d, 32, randomly_sample=True, density_noise_std=float(g["noise_std"]),
+                                  u=g["u"].to(dev), noise=g["noise"].to(dev))
+    loss = ((pixels - g["target"].to(dev).unsqueeze(1)) ** 2).mean()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6
+    loss.backward()
+    # the reference's fp32 gradients against the fp64 oracle on the same inputs: the gate-noise floor of this fixture
+    cfg = dict(O.default_config(), **kw)
+    p64 = {k: v.double().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    O.training_loss(p64, cfg, g["rays_o"].double(), g["rays_d"].double(), 32, g["target"].double(), g["u"].double(),
+                    g["noise"].double(), float(g["noise_std"])).backward()
+    floor = max(rel_err(g["grad." + k], p64[k].grad.float()) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad.cpu(), g["grad." + k])
+        assert e <= 5e-6 + 8 * floor, (k, e, floor)
+
+
 def test_shapes_the_kernels_do_not_take_are_refused():
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")

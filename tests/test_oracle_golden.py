@@ -129,3 +129,33 @@ def test_statics():
     for s in (64, 128, 192):
         assert torch.equal(O.sample_t(p, 1, s)[0], g[f"t{s}"])
     assert abs(float(O.box_diagonal(p)) - 69.28203) < 1e-4
+
+
+NARROW = {"h128": dict(hidden_size=128), "h64": dict(hidden_size=64, encoding_size=16, segmentation_outputs=7),
+          "h40": dict(hidden_size=40, encoding_size=10, segmentation_outputs=3)}
+
+
+@pytest.mark.parametrize("tag", sorted(NARROW))
+def test_narrow_networks_match_the_reference(tag):
+    """Fixture G11: `NeRF(hidden_size=.., encoding_size=.., segmentation_outputs=..)` of the reference itself
+    (nerf/model.py:471-475) — render, per-sample field, training loss and all 22 gradients — pins the oracle at the
+    network shapes the narrow kernel instantiations are tested against."""
+    g = load_golden("g11_narrow_" + tag)
+    cfg = dict(O.default_config(), **NARROW[tag])
+    params = {k[6:]: v for k, v in g.items() if k.startswith("param.")}
+    with torch.no_grad():
+        rgb, seg_out, st = O.render_rays(params, cfg, g["rays_o"], g["rays_d"], 48, return_stages=True)
+    assert (st["density"] - g["density"]).abs().max() <= 1e-5 * max(1.0, float(g["density"].abs().max()))
+    assert (st["color"] - g["color"]).abs().max() <= 1e-5 * max(1.0, float(g["color"].abs().max()))
+    ok = stable_rays(g["last_density"])
+    assert ok.sum() >= 48
+    assert (rgb - g["rgb"])[ok].abs().max() <= RGB_TOL
+    assert (seg_out - g["seg_out"])[ok].abs().max() <= 2e-5
+    p = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    loss = O.training_loss(p, cfg, g["rays_o"], g["rays_d"], 32, g["target"], g["u"], g["noise"], float(g["noise_std"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-6
+    loss.backward()
+    for k, v in p.items():
+        if v.grad is not None:
+            ref = g["grad." + k]
+            assert (v.grad - ref).abs().max() <= 2e-5 * ref.abs().max().clamp(min=1e-12), k
