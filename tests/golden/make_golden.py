@@ -228,28 +228,39 @@ def main():
     # — what the kernels instantiated at 8 and 4 register tiles per sample are held to (weights x 2: sharper fields)
     for tag, kw in (("h128", dict(hidden_size=128)), ("h64", dict(hidden_size=64, encoding_size=16, segmentation_outputs=7)),
                     ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3))):
-        torch.manual_seed(21)
-        m = NeRF(**kw)
-        with torch.no_grad():
-            for slot in LINEAR_SLOTS:
-                m.prediction_heads[slot].weight.mul_(2.0)
+        # A gradient is discontinuous in every ReLU gate, and a gate within rounding of zero (|gamma x_hat + beta| ~ 1e-7)
+        # falls on either side depending on the summation order of the LayerNorm that feeds it: the fixture takes the
+        # first seed whose training render has NO gate closer to zero than 2e-6 (read with forward hooks on the
+        # reference's LayerNorm modules), so that its gradients pin arithmetic, not coin flips.
+        for seed in range(21, 200):
+            torch.manual_seed(seed)
+            m = NeRF(**kw)
+            with torch.no_grad():
+                for slot in LINEAR_SLOTS:
+                    m.prediction_heads[slot].weight.mul_(2.0)
+            closest = []
+            hooks = [m.prediction_heads[i].register_forward_hook(lambda mod, inp, out: closest.append(float(out.abs().min())))
+                     for i in (1, 4, 7, 10, 13)]
+            torch.manual_seed(22)
+            u = torch.rand(64, 32)
+            noise = torch.randn(64, 31, 1)
+            target = torch.rand(64, 3)
+            # the reference's render_rays draws rand [N,S] then randn [N,S-1,1] (model.py:432, :652): replay them
+            torch.manual_seed(22)
+            pix, _ = m.render_rays(rays_o, rays_d, 32, randomly_sample=True, density_noise_std=0.5)
+            for hk in hooks:
+                hk.remove()
+            if min(closest) > 2e-6:
+                break
         st = stages(m, rays_o, rays_d, 48)
-        torch.manual_seed(22)
-        u = torch.rand(64, 32)
-        noise = torch.randn(64, 31, 1)
-        target = torch.rand(64, 3)
-        # the reference's render_rays draws rand [N,S] then randn [N,S-1,1] (model.py:432, :652): replay them
-        torch.manual_seed(22)
-        pix, _ = m.render_rays(rays_o, rays_d, 32, randomly_sample=True, density_noise_std=0.5)
         loss = ((pix - target.unsqueeze(1)) ** 2).mean()
         m.zero_grad()
         loss.backward()
         save("g11_narrow_" + tag, rays_o=rays_o, rays_d=rays_d, u=u, noise=noise, noise_std=0.5, target=target,
              loss=loss.detach(), rgb=st["rgb"], seg_out=st["seg_out"], density=st["density"], color=st["color"],
-             last_density=st["last_density"],
+             last_density=st["last_density"], init_seed=seed, closest_gate=min(closest),
              **{"param." + k: v for k, v in m.state_dict().items()},
              **{"grad." + k: p.grad for k, p in m.named_parameters()})
-
 
 if __name__ == "__main__":
     main()
