@@ -7,8 +7,9 @@ fixture tests/golden/g9_legacy_checkpoint.npz) on the upper hemisphere at the ch
 A fresh LegacyNeRF8x256 is then trained on them with nerf_amd.trainer.Trainer exactly as the notebook does.
 BASELINE.md's curve for the real data set: ~8 dB at 0, ~23 dB at 1,000, ~32 dB at 40,000 iterations.
 
-usage: python scripts/train_lego_standin.py [iterations] [fp32|f16x3] [graph|eager] [legacy8x256|mipnerf]
-(mipnerf: the generation-C network of nerf/model.py on the same views — its own log-spaced samples, no near / far)
+usage: python scripts/train_lego_standin.py [iterations] [fp32|f16x3] [graph|eager] [legacy8x256|mipnerf|mipnerf128]
+(mipnerf: the generation-C network of nerf/model.py on the same views — its own log-spaced samples, no near / far;
+ mipnerf128: the same with hidden_size=128, i.e. through the kernels instantiated at 8 register tiles per sample)
 writes gpurun_out/lego_standin_<arith>_<graph|eager>_<iterations>.json (iterations, PSNR, seconds) and the same
 name .png (held-out view: truth | render)."""
 import json, math, os, sys, time
@@ -64,9 +65,9 @@ print(f"stand-in scene: {VIEWS} views {H}x{W} rendered from examples/nerf.pth, m
 
 # ---- the notebook's run ------------------------------------------------------------------------------
 torch.manual_seed(0)
-if network == "mipnerf":
+if network.startswith("mipnerf"):
     from nerf_amd import NeRF
-    student = NeRF(focal_length=FOCAL).to(dev)
+    student = NeRF(focal_length=FOCAL, hidden_size=int(network[7:] or 256)).to(dev)
 else:
     student = LegacyNeRF8x256().to(dev)                   # fresh PyTorch-default initialisation
 student.train_precision = arith
