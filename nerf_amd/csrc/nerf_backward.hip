@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
         ba.gb_partial[(int64_t)blockIdx.x * kGbFloats + i] = gb[i];
 }
 
-// The same chain for a network that trains at 8 register tiles per sample (hidden_size <= 128, fp32 arithmetic;
+// The same chain for a network that trains at 8 register tiles per sample (hidden_size <= 128, fp32 arithmetic here;
 // nerf_device.h: train_tiles): saved rows 128 wide, the transposed narrow image (nerf_layout.h: kNarrowBwd8Offset:
 // 2 stages for layer 5, 4 per hidden layer).  The wave-ordered gamma / beta adds of a layer ride on the four stage
 // barriers of the hidden loop that follows it; layer 0's have no such loop behind them (the next item opens with
@@ -735,7 +735,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     ba.d_raw = args->d_raw;
     ba.intervals = a.num_samples - 1;
     ba.chunks = (ba.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
-    const int tt = train_tiles(shape_of(a).hidden, a.precision);      // 8: a narrow network in fp32 arithmetic, at its own cost
+    const int tt = train_tiles(shape_of(a).hidden);      // 8: a narrow network (hidden_size <= 128), at its own cost
     ba.L = make_train_layout(a.n_rays, ba.chunks, 16 * tt);
     ba.groups = ba.L.mp / 16 / kWavesPerWg;                 // (padded ray, chunk) items / 4 waves
     const int64_t slots = ba.L.mp / 16 / ba.chunks;         // padded rays

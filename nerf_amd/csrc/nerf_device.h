@@ -73,7 +73,7 @@ struct TrainLayout {
 };
 
 // `width`: features per saved x_hat / dY row — 256, or 128 when a narrow network (hidden_size <= 128) trains at its
-// own cost (fp32 arithmetic; nerf_layout.h: Narrow<8>): half the bytes of the step's dominant tensors.  The
+// own cost (both arithmetics; nerf_layout.h: Narrow<8>): half the bytes of the step's dominant tensors.  The
 // workspace the caller allocates is always sized for 256 (nerf_hip_train_workspace_bytes has no shape argument).
 __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chunks, int width = kHidden) {
     TrainLayout t;
@@ -92,10 +92,7 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
 }
 // register tiles per sample the TRAINING kernels of a launch run at: 8 for a narrow network (hidden_size <= 128;
 // <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator tiles), else 16
-__host__ __device__ inline int train_tiles(int hidden, int precision) {
-    (void)precision;            // (both arithmetics have their narrow kernels)
-    return hidden <= 128 ? 8 : 16;
-}
+__host__ __device__ inline int train_tiles(int hidden) { return hidden <= 128 ? 8 : 16; }      // (both arithmetics)
 
 // Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the
 // [16 samples][256 features] tile of a wave is stored as its 16 register tiles T, 1 KiB each — so one vector-memory

@@ -347,19 +347,19 @@ __device__ __forceinline__ void layer_out_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (
 // kPerSample: the instantiation that also writes the optional per-sample outputs (NeRF.forward's
 // tensors, compositing weights for the hierarchical resampler, debug outputs); the render-only
 // instantiations carry none of that code or its registers.
-// Narrow inference kernels (NT < 16, render-only): a TWO-slot weight ring (48.25 KiB of LDS) and <= 168 registers, so
-// that THREE workgroups share a CU — with a third of the MFMA work per chunk, the per-sample VALU phases (encoding,
-// LayerNorm finishing, compositing) need a second partner to hide under.
-template <bool kTrain, bool kPerSample, int NT>
+// Narrow kernels without per-sample outputs (NT < 16: render and training forward): a TWO-slot weight ring (48.25 KiB
+// of LDS) and <= 168 registers, so that THREE workgroups share a CU — with a third of the MFMA work per chunk, the
+// per-sample VALU phases (encoding, LayerNorm finishing, compositing) need a second partner to hide under.
+template <bool kPerSample, int NT>
 constexpr bool three_per_cu() { return NT < 16 && !kPerSample; }
 
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
-__global__ __launch_bounds__(256, (three_per_cu<kTrain, kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
+__global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     static_assert(NT != 4 || (!kTrain && !kHalf), "4 register tiles: fp32 inference only (training and the "
                                                   "split-precision arithmetic run at 8 or 16)");
     typedef Narrow<NT> N;
-    constexpr int kDepth = three_per_cu<kTrain, kPerSample, NT>() ? 2 : 3;
+    constexpr int kDepth = three_per_cu<kPerSample, NT>() ? 2 : 3;
     constexpr int kRingB = kDepth * kStageBytes, kLdsB = kRingB + kSmallLdsBytes;
     // (the split-precision kernel's LDS stash of per-lane state exists for the 256-register full-width kernel; at
     //  8 register tiles the state stays in registers)
@@ -1001,7 +1001,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     const bool train = a.train_workspace != nullptr;
-    const int tt = train_tiles(shape_of(a).hidden, a.precision);       // training: 8 or 16 register tiles per sample
+    const int tt = train_tiles(shape_of(a).hidden);       // training: 8 or 16 register tiles per sample
     ka.save = make_train_layout(a.n_rays, ka.chunks, 16 * tt);
     ka.norm = norm_divisor(shape_of(a).hidden);
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
