@@ -124,11 +124,12 @@ __host__ __device__ inline Shape shape_of(const NerfHipRenderArgs& a) {
 }
 struct NormDivisor {
     float inv_n;                // 1 / hidden_size (features beyond it are padding: exactly 0 before normalisation)
+    int32_t real;               // hidden_size: feature f of a sample is real for f < real (the cold variance pass masks by it)
 };
 __host__ __device__ inline NormDivisor norm_divisor(int hidden) {
-    return NormDivisor{1.0f / (float)hidden};
+    return NormDivisor{1.0f / (float)hidden, hidden};
 }
-constexpr NormDivisor kFullWidth = {1.0f / 256.0f};
+constexpr NormDivisor kFullWidth = {1.0f / 256.0f, 256};
 
 // ---------------------------------------------------------------------------------------------
 // weight stream: global -> LDS by LDS-DMA, two stages ahead of the MFMAs
@@ -139,6 +140,7 @@ constexpr NormDivisor kFullWidth = {1.0f / 256.0f};
 // still fly at the next hand-over (vmcnt(0 + younger)).
 template <int kStagesInImage, int kDepth = 3>
 struct WeightPipe {
+    static constexpr int kRingDepth = kDepth;
     const char* blob;           // packed image, stage 0
     char* ring;                 // LDS ring base
     int issue_stage;            // next stage of the image to issue (cyclic)
@@ -210,12 +212,15 @@ struct WeightPipe {
     // issue order (checked on the hardware: scripts/probes/vmcnt_order.hip), so without it the wait
     // also covers those stores (an HBM write latency per stage, which a 0.4 us split-precision stage
     // cannot hide); an under-count only makes the wait stricter, an over-count would let the stage be
-    // read before it has landed.
+    // read before it has landed.  WHICH operations are younger depends on the ring depth: with 3 slots the DMA of the
+    // stage being opened was issued two hand-overs ago (the stores of the previous stage and of this one are younger),
+    // with 2 slots one hand-over ago (only this stage's are) — callers count with Pipe::kRingDepth.  The wait carries
+    // its ring depth as an assembler comment, which nerf_amd/isa_scan.py (rule R6) reads back from the emitted code.
     template <int kYounger = 0>
     __device__ __forceinline__ const f32x4* open_stage() {
         static_assert(kYounger >= 0 && 4 + kYounger <= 63, "vmcnt immediate");
         static_assert(kDepth == 3 || kDepth == 2, "ring depth");
-        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" ::"n"((kDepth == 3 ? 4 : 0) + kYounger) : "memory");
+        asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0) ; nerf_ring_depth=%c1" ::"n"((kDepth == 3 ? 4 : 0) + kYounger), "n"(kDepth) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const f32x4* p = (const f32x4*)(ring + read_slot * kStageBytes) + lane;

@@ -123,7 +123,7 @@ __device__ __forceinline__ void interleave_7() {
 
 // Moments -> the deferred normalisation of `raw` (the layer's finished accumulators).
 // var = E[x^2] - mean^2 cancels when |mean| >> std, so whenever the mean carries more than 3/4 of
-// the second moment in ANY sample of the wave, a mean-shifted second pass is taken instead
+// the second moment in ANY sample of the wave, a second pass (the two-pass variance) is taken instead
 // (wave-uniform branch; pre-LayerNorm activations of this network have |mean| well below std, so
 // it is cold).  1/sqrt: hardware estimate (1 ulp) + one Newton step.
 template <bool kTrain, class Mom, int kOrder = kOrderNormRelu, int NT = 16>
@@ -136,18 +136,25 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
     const float ex2 = group_sum(m.sum_sq()) * nd.inv_n;
     float var = ex2 - mean * mean;
     if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
-        // second pass, mean-shifted:  sum (x - mean) x  =  sum (x - mean)^2  (because sum (x - mean) = 0): its rounding
-        // error is eps (1 + |mean| / std) of the variance against eps (1 + mean^2 / var) of the one-pass form above.
-        // Written with x as the second factor so that a narrower network's padded features — exactly 0 here — add
-        // exactly nothing: no mask per element (+790 instructions per kernel when tried), and no "sum all 256, subtract
-        // padded * mean^2" (which brings the cancellation back, amplified by padded / hidden: ADVICE r4).
+        // second pass, the true two-pass form sum (x - mean)^2 over the REAL features: an error d in the rounded mean
+        // enters as hidden * d^2 (second order: the cross term is d * sum (x - mean) = 0), so the variance keeps its
+        // ~eps relative error however large |mean| / std is — sum (x - mean) x, which this branch used in round 5, is
+        // first-order in d (error d * mean * hidden: the amplification mean^2 / var of the one-pass form again;
+        // ADVICE r5).  A narrower network's padded features are exactly 0 here and would each add mean^2, so they are
+        // masked by feature index (lane group g holds features 16 T + 4 g + r): two more VALU per element, in a
+        // branch that is cold — the pre-LayerNorm activations of this network have |mean| well below std.
+        // (the mask as integer arithmetic — sign bits of 16 T + r - (real - 4 g), ANDed onto the difference — not as
+        //  compares: 4 NT lane masks in scalar registers are what the narrow kernels, at their register limit, lack)
+        const int lim = nd.real - 4 * g;
         float v = 0.f;
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = kOrder == kOrderReluNorm ? __builtin_fmaxf(raw[T][r], 0.f) : raw[T][r];
-                v = __builtin_fmaf(x - mean, x, v);
+                const int real_bits = __builtin_amdgcn_sbfe(16 * T + r - lim, 31, 1);      // -1 for a real feature, else 0
+                const float d = __builtin_bit_cast(float, __builtin_bit_cast(int, x - mean) & real_bits);
+                v = __builtin_fmaf(d, d, v);
             }
         }
         var = group_sum(v) * nd.inv_n;
@@ -232,10 +239,13 @@ __device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4
             if (U + kSets - 1 < kUnits) {
                 const int ip = (i + kSets - 1) % 8, pset = (U + kSets - 1) % kSets;
                 if (ip == 0) {
-                    // training: the x_hat stores of this stage (units 1 and 3, before this hand-over)
-                    // and of the previous one are younger than the DMA of the stage being opened
+                    // training: the x_hat stores of this stage (units 1 and 3, before this hand-over) are younger
+                    // than the DMA of the stage being opened — and so are those of the previous stage when that DMA
+                    // was issued two hand-overs ago (3-slot ring); with 2 slots it was issued at the previous
+                    // hand-over, BEHIND the previous stage's stores, which therefore must not be counted
                     constexpr bool kStores = kTrain && kNormIn;
-                    const bool mine = kStores && build_next, prev = kStores && s >= 1 && s - 1 < KB - 1;
+                    const bool mine = kStores && build_next;
+                    const bool prev = Pipe::kRingDepth == 3 && kStores && s >= 1 && s - 1 < KB - 1;
                     if (mine && prev) st = (const h8*)pipe.template open_stage<4>();
                     else if (mine || prev) st = (const h8*)pipe.template open_stage<2>();
                     else st = (const h8*)pipe.open_stage();

@@ -27,14 +27,17 @@ scripts/probes/pk_vs_mfma_coexec.hip (compiler-generated code must obey it too):
       op_sel_hi (the HIGH result selecting a LOW register) is unaffected.  The kernels are built
       with -fno-slp-vectorize (nerf_amd/build.py), which is what keeps hipcc from producing the form.
 
-and one rule about the hand-written COUNTED waits (`s_waitcnt vmcnt(N)`, N > 4, inside asm: the
-stage hand-overs of WeightPipe::open_stage<kYounger>), whose immediates hard-code how many
-vector-memory operations the COMPILER emits between two LDS-DMA issues:
+and one rule about the hand-written COUNTED waits (`s_waitcnt vmcnt(N)` inside asm: the stage hand-overs of
+WeightPipe::open_stage<kYounger>), whose immediates hard-code how many vector-memory operations the COMPILER
+emits between two LDS-DMA issues.  A hand-over wait names the depth D of its weight ring in an assembler
+comment (`; nerf_ring_depth=D`, nerf_device.h); a counted wait without the comment is taken as D = 3:
 
   R6  the N youngest vector-memory instructions in front of such a wait (program text order), when
-      they include compiler-emitted loads / stores, contain at most ONE stage's LDS-DMA (4
-      global_load_lds): with more, N over-counts and the wait would leave pieces of the stage being
-      opened in flight.  (An under-count only makes the wait stricter.)
+      they include compiler-emitted loads / stores, contain at most D - 2 stages' LDS-DMA pieces
+      (4 global_load_lds per stage): with 3 slots the DMA of the FOLLOWING stage may still fly, with 2
+      slots nothing of any DMA may (the stage being opened was issued at the previous hand-over).
+      With more, N over-counts and the wait would leave pieces of the stage being opened in flight.
+      (An under-count only makes the wait stricter.)
 
 WINDOW = 20 covers the largest requirement of the MFMAs used here (8-pass XDL: 12).
 CLI: python scripts/isa_hazards.py [-DNAME ...]      exit code 1 when a rule is violated.
@@ -112,14 +115,17 @@ def scan(path):
             vmem.append((op.startswith(("global_load_lds", "buffer_load")) and "lds" in s, in_asm))
         if in_asm and op == "s_waitcnt":
             cnt = re.search(r"vmcnt\((\d+)\)", s)
-            if cnt and int(cnt.group(1)) > 4:
+            depth = re.search(r"nerf_ring_depth=(\d+)", s)
+            allowed = 4 * ((int(depth.group(1)) if depth else 3) - 2)     # LDS-DMA pieces the wait may leave in flight
+            if cnt and int(cnt.group(1)) > allowed:
                 n = int(cnt.group(1))
                 young = vmem[-n:]
                 if unknown_history and len(young) < n:       # what the block did not issue itself: assumed LDS-DMA pieces
                     young = [(True, False)] * (n - len(young)) + young
-                if any(not dma for dma, _ in young) and sum(dma for dma, _ in young) > 4:
+                if any(not dma for dma, _ in young) and sum(dma for dma, _ in young) > allowed:
                     found.append((kern, ln, s, "R6", f"the {cnt.group(1)} youngest vector-memory ops hold "
-                                  f"{sum(dma for dma, _ in young)} LDS-DMA pieces: the count is too high"))
+                                  f"{sum(dma for dma, _ in young)} LDS-DMA pieces (a {allowed // 4 + 2}-slot ring allows "
+                                  f"{allowed}): the count is too high"))
         if op.startswith("v_pk_") and op.endswith("_f32"):
             sel = re.search(r"op_sel:\[([01,]+)\]", s)
             if sel and "1" in sel.group(1):
@@ -181,12 +187,16 @@ def scan(path):
 
 
 def scratch_report(path):
-    """-> {kernel: (scratch bytes per lane, scratch accesses between two MFMAs)} of one kept assembly file.
+    """-> {kernel: (scratch bytes per lane, scratch accesses between two MFMAs, scratch instructions in the kernel)}
+    of one kept assembly file.
     Bytes = the kernel descriptor's `.amdhsa_private_segment_fixed_size`; "between two MFMAs" = scratch_load /
     scratch_store instructions with an MFMA within 40 instructions on BOTH sides, i.e. inside an MFMA loop proper
     (the VALU phases between two loops — LayerNorm, encoding, compositing — are hundreds of instructions long).
     A spill inside a loop is a vector-memory operation in the in-order vmcnt queue of the stage hand-overs; one in a
-    VALU phase costs its issue slot.  tests/test_build_hygiene.py holds every kernel to a budget."""
+    VALU phase costs its issue slot.  A frame WITHOUT any scratch instruction is not a spill: LLVM keeps the stack
+    slot of a scalar-register tuple it then parked in vector-register lanes (`SGPRs Spill` in the resource remarks,
+    `VGPRs Spill: 0`), plus the 4 bytes its register scavenger reserves once a frame exists — no lane ever touches
+    that memory.  tests/test_build_hygiene.py holds every kernel to a budget."""
     import bisect
     text = open(path).read()
     sizes = {}
@@ -196,16 +206,17 @@ def scratch_report(path):
     for name, size in sizes.items():
         start = text.find("\n" + name + ":")
         if start < 0:
-            out[name] = (size, 0)
+            out[name] = (size, 0, 0)
             continue
         ops = [x.strip() for x in text[start:text.index(".Lfunc_end", start)].splitlines()]
         mf = [i for i, x in enumerate(ops) if x.startswith("v_mfma")]
-        near = 0
+        near = total = 0
         for i, x in enumerate(ops):
-            if x.startswith("scratch_") and mf:
-                k = bisect.bisect_left(mf, i)
-                if 0 < k < len(mf) and i - mf[k - 1] <= 40 and mf[k] - i <= 40:
-                    near += 1
-        out[name] = (size, near)
+            if x.startswith("scratch_"):
+                total += 1
+                if mf:
+                    k = bisect.bisect_left(mf, i)
+                    if 0 < k < len(mf) and i - mf[k - 1] <= 40 and mf[k] - i <= 40:
+                        near += 1
+        out[name] = (size, near, total)
     return out
-

@@ -39,6 +39,7 @@ def resources(source, csrc=None, defines=()):
             ops = [x.strip() for x in body.splitlines()]
             mf = [i for i, x in enumerate(ops) if x.startswith("v_mfma")]
             info["mfma"] = len(mf)
+            info["scratch_instructions"] = sum(1 for x in ops if x.startswith("scratch_"))
             info["scratch_in_loops"] = sum(1 for i, x in enumerate(ops) if x.startswith("scratch_") and mf and mf[0] < i < mf[-1])
             # inside an MFMA loop proper: an MFMA within 40 instructions on BOTH sides (phases between two loops,
             # LayerNorm / encoding / compositing, are hundreds of instructions long)
@@ -68,4 +69,4 @@ if __name__ == "__main__":
             continue
         short = re.sub(r"^_ZN?\d*_GLOBAL__N_1", "", row["name"])[:70]
         print(f"{short:70s} vgpr {row.get('vgpr')} agpr {row.get('agpr')} sgpr {row.get('sgpr')} scratch {row.get('scratch')} "
-              f"(first..last MFMA: {row.get('scratch_in_loops')}, between MFMAs: {row.get('scratch_between_mfmas')}) waves/SIMD {row.get('occupancy')} mfma {row.get('mfma')}")
+              f"(instructions: {row.get('scratch_instructions')}, first..last MFMA: {row.get('scratch_in_loops')}, between MFMAs: {row.get('scratch_between_mfmas')}) waves/SIMD {row.get('occupancy')} mfma {row.get('mfma')}")

@@ -83,6 +83,16 @@ def test_scanner_flags_an_overcounted_handover_wait(tmp_path):
     rot_bad.write_text(jumped + wait % 7)          # 6 unseen operations may all be pieces of the opened stage
     assert haz.scan(str(rot_ok)) == []
     assert [h[3] for h in haz.scan(str(rot_bad))] == ["R6"]
+    # a TWO-slot ring (`; nerf_ring_depth=2` on the wait, nerf_device.h): the DMA of the opened stage was issued at
+    # the previous hand-over, so only what follows it may fly and NO piece of any DMA may (the narrow
+    # split-precision training forward counted the previous stage's stores too and left two pieces in flight)
+    wait2 = "\t;;#ASMSTART\n\ts_waitcnt vmcnt(%d) lgkmcnt(0) ; nerf_ring_depth=2\n\t;;#ASMEND\n"
+    body2 = "_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n" + stores * 2 + dma + stores * 2
+    two_ok, two_bad = tmp_path / "two_ok.s", tmp_path / "two_bad.s"
+    two_ok.write_text(body2 + wait2 % 2)
+    two_bad.write_text(body2 + wait2 % 4)          # the round-5 count: [piece, piece, store, store]
+    assert haz.scan(str(two_ok)) == []
+    assert [h[3] for h in haz.scan(str(two_bad))] == ["R6"]
     pure = tmp_path / "pure.s"                     # DMA-only waits (the weight gradient's ring) are by construction
     pure.write_text("_Zkernel:\n\ts_mov_b32 m0, s9\n\ts_nop 2\n" + dma + dma + wait % 8)
     assert haz.scan(str(pure)) == []
@@ -179,6 +189,15 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
 }
 
 
+# A frame that NO instruction touches is not a spill: LLVM keeps the stack slot of a scalar-register tuple it then parked
+# in vector-register lanes (resource remarks: `SGPRs Spill: 48`, `VGPRs Spill: 0`; MIR after prologepilog: one dead
+# 32-byte spill slot + the 4 bytes the register scavenger reserves once a frame exists).  Listed so that it cannot
+# grow or start being used unnoticed: (bytes, 0 scratch instructions).
+DEAD_FRAMES = {
+    "nerf_render_fwd_kernelILb1ELb1ELb0ELi8E": 36,      # narrow split-precision training forward, three workgroups per CU
+}
+
+
 def test_scratch_stays_within_the_per_kernel_budget():
     import glob
     import re
@@ -188,17 +207,24 @@ def test_scratch_stays_within_the_per_kernel_budget():
     files = sorted(glob.glob(os.path.join(nerf_build.OUT + ".obj", "*.s")))
     assert len(files) == len(nerf_build.sources())
     for path in files:
-        for kernel, (size, inside) in isa_scan.scratch_report(path).items():
+        for kernel, (size, inside, instructions) in isa_scan.scratch_report(path).items():
             short = re.sub(r"^_ZN?\d*_GLOBAL__N_1\d+", "", kernel)
+            dead = [k for k in DEAD_FRAMES if short.startswith(k)]
+            if dead:
+                seen.add(dead[0])
+                assert instructions == 0 and size <= DEAD_FRAMES[dead[0]], (kernel, size, instructions)
+                continue
             keys = [k for k in SCRATCH_BUDGET if short.startswith(k)]
             if not keys:
-                assert (size, inside) == (0, 0), f"{kernel} spills ({size} B per lane, {inside} accesses inside its MFMA loops)"
+                assert (size, inside, instructions) == (0, 0, 0), \
+                    f"{kernel} spills ({size} B per lane, {instructions} scratch instructions, {inside} inside its MFMA loops)"
                 continue
             key = max(keys, key=len)
             seen.add(key)
             budget = SCRATCH_BUDGET[key]
             assert size <= budget[0] and inside <= budget[1], (kernel, (size, inside), budget)
-    assert seen == set(SCRATCH_BUDGET), set(SCRATCH_BUDGET) - seen      # a kernel that no longer spills: delete its entry
+    # a kernel that no longer spills: delete its entry
+    assert seen == set(SCRATCH_BUDGET) | set(DEAD_FRAMES), (set(SCRATCH_BUDGET) | set(DEAD_FRAMES)) - seen
 
 
 def test_workspace_mirror_matches_the_library():
