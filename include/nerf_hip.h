@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 7
+#define NERF_HIP_ABI_VERSION 8
 
 #define NERF_HIP_OK 0
 #define NERF_HIP_EINVAL (-1)   /* bad argument (null pointer, size out of range)      */
@@ -317,9 +317,27 @@ int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream);
 
 /* Average duration in milliseconds of the render kernel over the launches issued since the
  * last call with reset != 0, measured with HIP events recorded on the launch stream.  Timing
- * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises. */
+ * is off by default (no events recorded); nerf_hip_timing(1) turns it on.  Synchronises.
+ * With timing on, every launch of a training step is bracketed the same way under one of the tags below
+ * (the training forward's network kernel counts as NERF_HIP_TIMING_FORWARD, like the render kernel);
+ * nerf_hip_timing_read reports that tag alone, nerf_hip_timing_read_tagged all of them
+ * (avg_ms / launches: arrays of n_tags entries, n_tags <= NERF_HIP_TIMING_TAGS).  No reference counterpart: the
+ * reference has no timers; bench.py's roofline and its per-kernel split of a training step
+ * (train_conditional_nerf.py:130-135) are measured with this. */
+#define NERF_HIP_TIMING_FORWARD 0             /* render kernel / training forward (network) of either network */
+#define NERF_HIP_TIMING_COMPOSITE_FORWARD 1   /* training: compositing forward (+ per-sample field outputs)    */
+#define NERF_HIP_TIMING_COMPOSITE_BACKWARD 2  /* compositing backward, or the d_raw scatter                     */
+#define NERF_HIP_TIMING_DATA_GRADIENT 3
+#define NERF_HIP_TIMING_WEIGHT_GRADIENT 4
+#define NERF_HIP_TIMING_REDUCE 5              /* split-K slabs -> the flat gradient                              */
+#define NERF_HIP_TIMING_ADAM 6
+#define NERF_HIP_TIMING_LOSS 7
+#define NERF_HIP_TIMING_PACK 8                /* parameter re-layout (either network)                            */
+#define NERF_HIP_TIMING_TAGS 9
 int nerf_hip_timing(int enable);
 int nerf_hip_timing_read(int reset, double* avg_ms, int64_t* launches);
+int nerf_hip_timing_read_tagged(int reset, int32_t n_tags, double* avg_ms, int64_t* launches);
+const char* nerf_hip_timing_tag_name(int32_t tag);      /* "forward", "data_gradient", ...; NULL out of range */
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NERF_HIP_LIB selects another build of the same ABI (an experimental variant: scripts/ab_libs.py)
 LIB_PATH = os.environ.get("NERF_HIP_LIB") or os.path.join(_HERE, "csrc", "libnerf_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 NUM_PARAM_TENSORS = 22
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # NERF_HIP_PRECISION_*
 
@@ -172,6 +172,11 @@ def lib():
     handle.nerf_hip_timing_read.restype = ctypes.c_int
     handle.nerf_hip_timing_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_int64)]
+    handle.nerf_hip_timing_read_tagged.restype = ctypes.c_int
+    handle.nerf_hip_timing_read_tagged.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.POINTER(ctypes.c_double),
+                                                   ctypes.POINTER(ctypes.c_int64)]
+    handle.nerf_hip_timing_tag_name.restype = ctypes.c_char_p
+    handle.nerf_hip_timing_tag_name.argtypes = [ctypes.c_int32]
     if handle.nerf_hip_version() != ABI_VERSION:
         raise RuntimeError(f"libnerf_hip.so ABI {handle.nerf_hip_version()} != expected {ABI_VERSION}")
     handle.nerf_hip_build_flags.restype = ctypes.c_char_p
@@ -195,7 +200,7 @@ EXPORTS = ("nerf_hip_version", "nerf_hip_last_error", "nerf_hip_build_flags", "n
            "nerf_hip_legacy_backward_scratch_bytes", "nerf_hip_legacy_render_backward", "nerf_hip_adam_step", "nerf_hip_mse_loss",
            "nerf_hip_rng_advance",
            "nerf_hip_timing",
-           "nerf_hip_timing_read")
+           "nerf_hip_timing_read", "nerf_hip_timing_read_tagged", "nerf_hip_timing_tag_name")
 
 
 def build_flags():
@@ -224,3 +229,16 @@ def timing_read(reset=True):
     check(lib().nerf_hip_timing_read(1 if reset else 0, ctypes.byref(avg), ctypes.byref(n)),
           "nerf_hip_timing_read")
     return avg.value, n.value
+
+
+TIMING_TAGS = 9         # NERF_HIP_TIMING_TAGS
+
+
+def timing_read_tagged(reset=True):
+    """{tag name: (average ms, launches)} of every launch kind recorded since the last reset (the launches of a
+    training step: forward, composite_forward, composite_backward, data_gradient, weight_gradient, reduce, adam,
+    loss, pack); tags without a launch are left out."""
+    avg = (ctypes.c_double * TIMING_TAGS)()
+    n = (ctypes.c_int64 * TIMING_TAGS)()
+    check(lib().nerf_hip_timing_read_tagged(1 if reset else 0, TIMING_TAGS, avg, n), "nerf_hip_timing_read_tagged")
+    return {lib().nerf_hip_timing_tag_name(t).decode(): (avg[t], n[t]) for t in range(TIMING_TAGS) if n[t] > 0}

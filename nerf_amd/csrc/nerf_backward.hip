@@ -783,27 +783,39 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;
     ba.data_grid = (int)grid;
 
-    if (ba.d_raw != nullptr)
-        hipLaunchKernelGGL(nerf_field_scatter_kernel, dim3((unsigned)((ba.L.mp * (kOutPad / 4) + 255) / 256)), dim3(256), 0, st, ba);
-    else
-        hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
-                           dim3(256), 0, st, ba);
-    if (half && tt == 8) hipLaunchKernelGGL(nerf_bwd_data_h_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
-    else if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
-    else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
-    else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_BACKWARD);
+        if (ba.d_raw != nullptr)
+            hipLaunchKernelGGL(nerf_field_scatter_kernel, dim3((unsigned)((ba.L.mp * (kOutPad / 4) + 255) / 256)), dim3(256), 0, st, ba);
+        else
+            hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
+                               dim3(256), 0, st, ba);
+    }
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_DATA_GRADIENT);
+        if (half && tt == 8) hipLaunchKernelGGL(nerf_bwd_data_h_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
+        else if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
+        else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+        else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+    }
     const int wgrad_jobs = 6;
     const bool wgrad_half = half;
-    if (tt == 8 && wgrad_half)
-        hipLaunchKernelGGL(nerf_wgrad_h_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
-    else if (tt == 8)
-        hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
-    else if (wgrad_half)
-        hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
-    else
-        hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
-    hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(shape_of(a)) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
-                       0, st, ba);
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_WEIGHT_GRADIENT);
+        if (tt == 8 && wgrad_half)
+            hipLaunchKernelGGL(nerf_wgrad_h_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+        else if (tt == 8)
+            hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+        else if (wgrad_half)
+            hipLaunchKernelGGL(nerf_wgrad_h_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+        else
+            hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+    }
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_REDUCE);
+        hipLaunchKernelGGL(nerf_grad_reduce_kernel, dim3((grad_elements(shape_of(a)) + kReduceThreads - 1) / kReduceThreads + kReduceGbBlocks), dim3(kReduceThreads),
+                           0, st, ba);
+    }
     return nerf_common::check_hip(hipGetLastError(), "render_backward launch");
 }
 

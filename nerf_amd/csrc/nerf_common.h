@@ -37,6 +37,7 @@ inline int check_hip(hipError_t e, const char* what) {
 struct Timing {
     struct Pair {
         hipEvent_t start, stop;
+        int tag;                // NERF_HIP_TIMING_* (include/nerf_hip.h): which launch of a step the pair brackets
     };
     static std::mutex& mu() {
         static std::mutex m;
@@ -62,6 +63,8 @@ struct Timing {
     static void before(hipStream_t st) {
         pending() = nullptr;
         if (!on().load(std::memory_order_relaxed)) return;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;       // a captured region is replayed, not timed
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
         {
             std::lock_guard<std::mutex> lk(mu());
             if (pairs().size() >= kMaxPairs) return;
@@ -71,7 +74,7 @@ struct Timing {
         (void)hipEventRecord(e, st);
         pending() = e;
     }
-    static void after(hipStream_t st) {
+    static void after(hipStream_t st, int tag = NERF_HIP_TIMING_FORWARD) {
         if (pending() == nullptr) return;
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) {
@@ -81,23 +84,31 @@ struct Timing {
         }
         (void)hipEventRecord(e, st);
         std::lock_guard<std::mutex> lk(mu());
-        pairs().push_back(Pair{pending(), e});
+        pairs().push_back(Pair{pending(), e, tag});
         pending() = nullptr;
     }
-    static int read(bool reset, double* avg_ms, int64_t* launches) {
+    // averages per tag over the pairs recorded since the last reset; avg_ms / launches: [n_tags]
+    static int read_tagged(bool reset, int n_tags, double* avg_ms, int64_t* launches) {
         std::lock_guard<std::mutex> lk(mu());
-        double total = 0.0;
-        int64_t n = 0;
+        for (int t = 0; t < n_tags; ++t) {
+            if (avg_ms) avg_ms[t] = 0.0;
+            if (launches) launches[t] = 0;
+        }
+        std::vector<double> total((size_t)(n_tags > 0 ? n_tags : 0), 0.0);
+        std::vector<int64_t> n((size_t)(n_tags > 0 ? n_tags : 0), 0);
         for (auto& p : pairs()) {
+            if (p.tag < 0 || p.tag >= n_tags) continue;
             if (hipEventSynchronize(p.stop) != hipSuccess) continue;
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
-                total += ms;
-                ++n;
+                total[(size_t)p.tag] += ms;
+                ++n[(size_t)p.tag];
             }
         }
-        if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
-        if (launches) *launches = n;
+        for (int t = 0; t < n_tags; ++t) {
+            if (avg_ms) avg_ms[t] = n[(size_t)t] ? total[(size_t)t] / (double)n[(size_t)t] : 0.0;
+            if (launches) launches[t] = n[(size_t)t];
+        }
         if (reset) {
             for (auto& p : pairs()) {
                 (void)hipEventDestroy(p.start);
@@ -107,6 +118,22 @@ struct Timing {
         }
         return NERF_HIP_OK;
     }
+    // the forward (render) kernel alone: what bench.py's roofline divides by
+    static int read(bool reset, double* avg_ms, int64_t* launches) {
+        double a[NERF_HIP_TIMING_TAGS];
+        int64_t n[NERF_HIP_TIMING_TAGS];
+        const int rc = read_tagged(reset, NERF_HIP_TIMING_TAGS, a, n);
+        if (avg_ms) *avg_ms = a[NERF_HIP_TIMING_FORWARD];
+        if (launches) *launches = n[NERF_HIP_TIMING_FORWARD];
+        return rc;
+    }
+};
+// One launch (or a short run of launches) between a pair of events, when timing is on
+struct TimedLaunch {
+    hipStream_t st;
+    int tag;
+    TimedLaunch(hipStream_t s, int t) : st(s), tag(t) { Timing::before(st); }
+    ~TimedLaunch() { Timing::after(st, tag); }
 };
 
 // Name of the experiment this library was built as ("" for the product build).  The product sources

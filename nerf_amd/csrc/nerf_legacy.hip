@@ -794,6 +794,7 @@ int nerf_hip_legacy_pack_weights(const float* const* params, float* packed, void
     }
     pa.packed = packed;
     const int threads = 256, blocks = (kLegacyPackedFloats + threads - 1) / threads;
+    nerf_common::TimedLaunch timed((hipStream_t)stream, NERF_HIP_TIMING_PACK);
     hipLaunchKernelGGL(nerf_legacy_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, pa);
     return nerf_common::check_hip(hipGetLastError(), "legacy_pack_weights launch");
 }
@@ -860,13 +861,13 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, ka);
+    nerf_common::Timing::after(st, NERF_HIP_TIMING_FORWARD);
     if (train) {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_FORWARD);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_legacy_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
     }
-    rc = nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
-    nerf_common::Timing::after(st);
-    return rc;
+    return nerf_common::check_hip(hipGetLastError(), "legacy_render_forward launch");
 }
 
 }  // extern "C"

@@ -588,19 +588,28 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
     if (grid > kMaxDataGrid) grid = kMaxDataGrid;
     ba.data_grid = (int)grid;
 
-    hipLaunchKernelGGL(nerf_legacy_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
-                       dim3(256), 0, st, ba);
-    if (half) {
-        hipLaunchKernelGGL(nerf_legacy_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes + 64, st, ba);
-        hipLaunchKernelGGL(nerf_legacy_wgrad_h_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
-                           kRingSlots * kRingSlotBytes, st, ba);
-    } else {
-        hipLaunchKernelGGL(nerf_legacy_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes, st, ba);
-        hipLaunchKernelGGL(nerf_legacy_wgrad_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
-                           kRingSlots * kRingSlotBytes, st, ba);
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_BACKWARD);
+        hipLaunchKernelGGL(nerf_legacy_composite_bwd_kernel, dim3((unsigned)((slots + kWavesPerWg - 1) / kWavesPerWg)),
+                           dim3(256), 0, st, ba);
     }
-    hipLaunchKernelGGL(nerf_legacy_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks),
-                       dim3(kReduceThreads), 0, st, ba);
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_DATA_GRADIENT);
+        if (half) hipLaunchKernelGGL(nerf_legacy_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes + 64, st, ba);
+        else hipLaunchKernelGGL(nerf_legacy_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kLBwdLdsBytes, st, ba);
+    }
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_WEIGHT_GRADIENT);
+        if (half) hipLaunchKernelGGL(nerf_legacy_wgrad_h_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
+                                     kRingSlots * kRingSlotBytes, st, ba);
+        else hipLaunchKernelGGL(nerf_legacy_wgrad_kernel, dim3(ba.splits * kWgradJobs), dim3(256),
+                                kRingSlots * kRingSlotBytes, st, ba);
+    }
+    {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_REDUCE);
+        hipLaunchKernelGGL(nerf_legacy_grad_reduce_kernel, dim3(kReduceDirectBlocks + kReduceGbBlocks),
+                           dim3(kReduceThreads), 0, st, ba);
+    }
     return nerf_common::check_hip(hipGetLastError(), "legacy_render_backward launch");
 }
 

@@ -971,6 +971,7 @@ int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t en
     }
     pa.packed = packed;
     const int threads = 256, blocks = (kPackedFloats + threads - 1) / threads + 1;    // + the bounds block
+    nerf_common::TimedLaunch timed((hipStream_t)stream, NERF_HIP_TIMING_PACK);
     hipLaunchKernelGGL(nerf_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, pa);
     return nerf_common::check_hip(hipGetLastError(), "pack_weights launch");
 }
@@ -1057,7 +1058,9 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, ka);
+    nerf_common::Timing::after(st, NERF_HIP_TIMING_FORWARD);
     if (train) {
+        nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_FORWARD);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
         hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
         if (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr) {
@@ -1065,15 +1068,26 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
             hipLaunchKernelGGL(nerf_field_outputs_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, ka);
         }
     }
-    rc = nerf_common::check_hip(hipGetLastError(), "render_forward launch");
-    nerf_common::Timing::after(st);
-    return rc;
+    return nerf_common::check_hip(hipGetLastError(), "render_forward launch");
 }
 
 int nerf_hip_timing(int enable) { return nerf_common::Timing::enable(enable != 0); }
 
 int nerf_hip_timing_read(int reset, double* avg_ms, int64_t* launches) {
     return nerf_common::Timing::read(reset != 0, avg_ms, launches);
+}
+
+int nerf_hip_timing_read_tagged(int reset, int32_t n_tags, double* avg_ms, int64_t* launches) {
+    if (n_tags < 0 || n_tags > NERF_HIP_TIMING_TAGS)
+        return nerf_common::fail(NERF_HIP_EINVAL, "timing_read_tagged: n_tags out of range");
+    return nerf_common::Timing::read_tagged(reset != 0, n_tags, avg_ms, launches);
+}
+
+const char* nerf_hip_timing_tag_name(int32_t tag) {
+    static const char* const names[NERF_HIP_TIMING_TAGS] = {
+        "forward", "composite_forward", "composite_backward", "data_gradient", "weight_gradient",
+        "reduce", "adam", "loss", "pack"};
+    return tag >= 0 && tag < NERF_HIP_TIMING_TAGS ? names[tag] : nullptr;
 }
 
 }  // extern "C"

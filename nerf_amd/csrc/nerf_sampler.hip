@@ -240,6 +240,7 @@ extern "C" int nerf_hip_adam_step(const NerfHipAdamArgs* args, void* stream) {
     AdamKernelArgs ka;
     ka.a = a;
     // every launch uses ALL the slots (idle workgroups only count), so the copies stay equal whatever `total` is
+    nerf_common::TimedLaunch timed((hipStream_t)stream, NERF_HIP_TIMING_ADAM);
     hipLaunchKernelGGL(nerf_adam_kernel, dim3(NERF_HIP_ADAM_STEP_SLOTS), dim3(256), 0, (hipStream_t)stream, ka);
     return nerf_common::check_hip(hipGetLastError(), "adam_step launch");
 }
@@ -261,6 +262,7 @@ extern "C" int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream) {
         return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null tensor");
     MseKernelArgs ka;
     ka.a = a;
+    nerf_common::TimedLaunch timed((hipStream_t)stream, NERF_HIP_TIMING_LOSS);
     hipLaunchKernelGGL(nerf_mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ka);
     return nerf_common::check_hip(hipGetLastError(), "mse_loss launch");
 }

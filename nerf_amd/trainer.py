@@ -199,11 +199,21 @@ class Trainer:
         loss.backward()
         return loss.detach()
 
+    def _global_n(self, batch, n):
+        """Rays of the GLOBAL batch this step belongs to: ``batch["global_n"]`` when the producer says (dataset.batches
+        always does); else — an external producer — the configured batch size when this rank holds its full share of
+        one (uneven shards: ``n * world`` would never equal it and every step would silently run eagerly),
+        and ``n * world`` only for a short batch, where nothing better is known."""
+        if "global_n" in batch:
+            return int(batch["global_n"])
+        if not self.distributed:
+            return n
+        return self.batch_size if n == self._full_share else n * self.world
+
     # ---- HIP-graph path ---------------------------------------------------------------------------
-    def _graph_body(self, o, d, pix):
+    def _graph_body(self, o, d, pix, u=None, noise=None):
         n, dev = o.shape[0], o.device
-        u = noise = None
-        if self.model.rng == "torch":
+        if u is None and self.model.rng == "torch":
             u, noise = self._draw(n, dev, None)           # graph-safe default generator
         self.last_draws = (u, noise)                      # (static tensors of the graph once captured; None: Philox)
         pixels = self._render(o, d, u, noise)
@@ -226,8 +236,12 @@ class Trainer:
         # baked in as share / batch_size; a short global batch can still hand SOME ranks their full share, and
         # those would replay with that weight while the others go eager with n / global_n — weights that no
         # longer sum to 1.  `global_n` is the same number on every rank, so all ranks take the same path.
-        global_n = int(batch.get("global_n", n if not self.distributed else n * self.world))
-        if n != self._full_share or (self.distributed and global_n != self.batch_size):
+        global_n = self._global_n(batch, n)
+        # a batch may bring its own draws (batch["u"] [n, S], batch["noise"]: a parity study replaying captured draws,
+        # tests/psnr_parity.py); they become static inputs of the graph, so every batch of the run must bring them
+        keys = ("rays_o", "rays_d", "pixels") + (("u", "noise") if "u" in batch else ())
+        if n != self._full_share or (self.distributed and global_n != self.batch_size) or \
+                (self._graph is not None and keys != tuple(self._static)):
             self._stale_grads = True                      # the eager step re-points p.grad
             return None
         if self._graph is None and self._eager_steps < 5:
@@ -239,19 +253,20 @@ class Trainer:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 self.optimizer.zero_grad(set_to_none=True)
-                loss = self._graph_body(batch["rays_o"], batch["rays_d"], batch["pixels"])
+                loss = self._graph_body(batch["rays_o"], batch["rays_d"], batch["pixels"], batch.get("u"), batch.get("noise"))
                 if self.distributed and not self.collective_in_graph:
-                    self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
+                    self.reduce(self.model.last_flat_grad, n / max(self._global_n(batch, n), 1))
                     self.optimizer.step()
             torch.cuda.current_stream().wait_stream(self._side)
             return loss
         if self._graph is None:
-            self._static = {k: batch[k].clone() for k in ("rays_o", "rays_d", "pixels")}
+            self._static = {k: batch[k].clone() for k in keys}
             self.optimizer.zero_grad(set_to_none=True)    # the gradients are created inside the graph's pool
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph, stream=self._side):
                 self._static_loss = self._graph_body(self._static["rays_o"], self._static["rays_d"],
-                                                     self._static["pixels"])
+                                                     self._static["pixels"], self._static.get("u"),
+                                                     self._static.get("noise"))
             self._graph_rays = n
             self._static_grads = [p.grad for p in self.model.parameters()]
             self._static_flat = self.model.last_flat_grad
@@ -264,7 +279,7 @@ class Trainer:
             self.model.last_flat_grad = self._static_flat
             self._stale_grads = False
         if self.distributed and not self.collective_in_graph:
-            self.reduce(self._static_flat, n / max(int(batch.get("global_n", n * self.world)), 1))
+            self.reduce(self._static_flat, n / max(self._global_n(batch, n), 1))
             self.optimizer.step()
         if getattr(self.model, "train_precision", "fp32") == "f16x3" and self.iteration % 64 == 0:
             self.model.check_split_precision_range()      # the replay runs no host code
@@ -276,8 +291,8 @@ class Trainer:
             if loss is not None:
                 return loss
         n = batch["rays_o"].shape[0]
-        u = noise = None
-        if self.model.rng == "torch":
+        u, noise = batch.get("u"), batch.get("noise")     # the caller's own draws, if it brings any
+        if u is None and self.model.rng == "torch":
             # the reference's draws in the reference's order (rand, then randn: nerf/model.py:432, :652):
             # from this rank's own generator when data-parallel, else from torch's default one
             u, noise = self._draw(n, batch["rays_o"].device, self.draws if self.distributed else None)
@@ -286,7 +301,7 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)       # p.grad become views of the flat gradient
         loss = self._loss_backward(pixels, batch["pixels"])
         if self.distributed:
-            self.reduce(self.model.last_flat_grad, n / max(int(batch.get("global_n", n * self.world)), 1))
+            self.reduce(self.model.last_flat_grad, n / max(self._global_n(batch, n), 1))
         self.optimizer.step()
         return loss.detach()
 

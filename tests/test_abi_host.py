@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(handle):
     for name in names:
         assert hasattr(handle, name), name
     assert set(_lib.EXPORTS) == set(names)
-    assert handle.nerf_hip_version() == _lib.ABI_VERSION == 7
+    assert handle.nerf_hip_version() == _lib.ABI_VERSION == 8
     # packed image = {74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB} x {fp32, f16 pairs}
     # + four bound constants + the narrow images: fp32 forward (21 stages at 8 register tiles, 7 at 4), transposed
     # fp32 (18 at 8), f16-pair forward (21) and transposed (18) at 8

@@ -44,7 +44,7 @@ def make_model(dev, scale=1.0, focal_length=112.0, params=None):
 
 def test_library_loaded_and_no_cpu_path(dev):
     from nerf_amd import _lib
-    assert _lib.lib().nerf_hip_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().nerf_hip_version() == _lib.ABI_VERSION == 8
     model = make_model(dev)
     with pytest.raises(RuntimeError):
         model.render_rays(torch.zeros(4, 3), torch.ones(4, 3), 8)

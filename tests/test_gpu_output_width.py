@@ -142,14 +142,14 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-@pytest.mark.parametrize("strength", [1.0, 15.0])
+@pytest.mark.parametrize("strength", [1.0, 20.0])
 @pytest.mark.parametrize("shape", [(50, 256, 32), (50, 128, 32), (7, 64, 16), (3, 40, 10)])
 def test_layer_norm_with_a_large_common_bias(shape, strength, precision):
     """The LayerNorm's variance: one-pass moments (E[x^2] - mean^2) cancel when |mean| >> std, so the kernels switch —
     wave-uniformly, whenever mean^2 > 0.75 E[x^2] in any sample — to the two-pass form sum (x - mean)^2 over the real
     features, a narrower network's zero-padded ones masked by feature index (nerf_amd/csrc/nerf_fused.h).  Default
     networks never enter that branch (|mean| well below std), so this test forces it: a large common bias on two
-    Linear layers — |mean| / std of 10 - 40 at their LayerNorms, and of 150 - 600 at ``strength`` 15, where a pass that
+    Linear layers — |mean| / std of 10 - 40 at their LayerNorms, and of 110 - 800 at ``strength`` 20, where a pass that
     is first-order in the rounding of the mean (round 5's sum (x - mean) x: error eps mean^2 / var) is
     off by 1e-3 and more — full width, both narrow instantiations and a padded width, forward and gradients against
     the oracle.  At that ratio the fp32 oracle itself feels the rounding of its inputs (a pre-activation of 90 +- 0.5
