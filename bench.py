@@ -188,7 +188,60 @@ def cpu_baseline():
             "config1_100x100x64": cpu_baseline_small(best["cores"])}
 
 
-def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_precision="fp32", hidden=256, enc=32):
+REPEATS = 5                       # every secondary timing: REPEATS loops of `steps` steps, median / min / max reported
+SHORT_STEPS = 50                  # steps per loop for anything under 10 ms
+FRAME_STEPS = 5                   # ... and for whole frames
+
+
+def spread(samples_ms):
+    """min / median / max of the per-loop averages (ms) — boxes of this pool differ by 4-6 %, so a single mean of a
+    5-10-step loop cannot decide a target that is 1-5 % away (round-5 verdict, weak 7)."""
+    v = sorted(samples_ms)
+    return {"median": v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]),
+            "min": v[0], "max": v[-1], "loops": len(v), "samples": [round(x, 5) for x in samples_ms]}
+
+
+def timed_loops(dev, fn, steps, repeats=REPEATS, fence=None):
+    """REPEATS synchronised loops of `steps` calls; the per-step average of each loop in ms."""
+    out = []
+    for _ in range(repeats):
+        if fence is not None:
+            fence()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        if fence is not None:
+            fence()
+        torch.cuda.synchronize(dev)
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return out
+
+
+def kernel_split(dev, fn, steps=20):
+    """Average duration of every launch kind of one step (HIP events on the launch stream around each launch:
+    nerf_hip_timing_read_tagged, include/nerf_hip.h) over `steps` extra, separately run steps — the events cost a
+    few microseconds each, so this pass is not the one `ms_per_step` comes from."""
+    from nerf_amd import _lib
+    torch.cuda.synchronize(dev)
+    _lib.timing(True)
+    _lib.timing_read_tagged(reset=True)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    tags = _lib.timing_read_tagged(reset=True)
+    _lib.timing(False)
+    out = {name: round(ms * n / steps, 5) for name, (ms, n) in tags.items()}      # ms per STEP (a kind may launch twice)
+    out["sum"] = round(sum(out.values()), 5)
+    return out
+
+
+def train_tiles_of(hidden):
+    """Register tiles per sample the TRAINING kernels of a network run at (nerf_amd/csrc/nerf_device.h: train_tiles)."""
+    return 16 if hidden > 128 else 8
+
+
+def train_step_timing(dev, rays=4096, samples=64, steps=SHORT_STEPS, warmup=5, train_precision="fp32", hidden=256, enc=32):
     """Secondary figure (BASELINE config 5 batch): one optimiser step = training forward + HIP
     backward + Adam on `rays` x `samples`; random rays/targets, stratified draws, noise std 1.
     `hidden` / `enc`: the constructor's hidden_size / encoding_size (nerf/model.py:471-475); a network of
@@ -212,23 +265,21 @@ def train_step_timing(dev, rays=4096, samples=64, steps=10, warmup=3, train_prec
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
+    ms = spread(timed_loops(dev, step, steps))
+    kernels = kernel_split(dev, step)
+    dt = ms["median"] * 1e-3
     flop = 2 * (3 * enc * hidden + 4 * hidden * hidden + 54 * hidden)
     tflops = 3 * flop * rays * (samples - 1) / dt / 1e12
+    timing = {"ms_per_step": ms["median"], "ms_per_step_spread": ms, "steps_per_loop": steps, "kernels_ms": kernels}
     if hidden != 256:
         return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam, hidden_size={hidden}, "
                             f"encoding_size={enc} ({flop} FLOP per sample)",
-                "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt, "tflops_fwd_dgrad_wgrad": tflops,
+                **timing, "ray_samples_per_s": rays * samples / dt, "tflops_fwd_dgrad_wgrad": tflops,
                 "arithmetic": ("fp32 MFMA forward and data gradient, bf16-triple weight gradient" if train_precision == "fp32"
-                               else "f16 pairs in all three kernels") + ", at 8 register tiles per sample with 128-wide "
-                              "saved rows (the network's own cost; hidden_size <= 64 trains at 128's)"}
+                               else "f16 pairs in all three kernels") + f", at {train_tiles_of(hidden)} register tiles per sample "
+                              "(the network's own cost)"}
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
-            "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
+            **timing, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
             "arithmetic": ("training forward, data gradient and weight gradient on f16 pairs (three f16 MFMAs per "
                            "product; layer 0's weight gradient on bf16 triples); fp32 accumulate everywhere"
@@ -260,12 +311,7 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
         opt.step()
 
     def timed(fn):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / steps
+        return spread(timed_loops(dev, fn, steps))
 
     def eager():
         opt.zero_grad(set_to_none=True)
@@ -287,11 +333,13 @@ def small_batch_step_timing(dev, rays=512, samples=64, steps=50, train_precision
     graph.replay()
     t_graph = timed(graph.replay)
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam, {train_precision}",
-            "ms_per_step_eager": t_eager * 1e3, "ms_per_step_graph": t_graph * 1e3,
-            "ray_samples_per_s_graph": rays * samples / t_graph}
+            "ms_per_step_eager": t_eager["median"], "ms_per_step_graph": t_graph["median"],
+            "eager_spread": t_eager, "graph_spread": t_graph, "steps_per_loop": steps,
+            "ray_samples_per_s_graph": rays * samples / (t_graph["median"] * 1e-3)}
 
 
-def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, samples=64, train_precision="f16x3"):
+def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, samples=64, train_precision="f16x3",
+                  scaling="strong"):
     """BASELINE config 5 as the N > 1 measurement: ONE 4096-ray batch per step, data-parallel over `world` ranks
     (rays rank * 4096 / world ... of the same batch on every rank), each rank running training forward + HIP backward
     on its share, then ONE in-place all-reduce of the flat 304,438-float gradient (nerf_amd/parallel.py), then the
@@ -299,7 +347,14 @@ def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, sa
     train_conditional_nerf.py:115-135.  Measured twice: launch by launch with the collective bracketed by events on
     the launch stream, and as ONE HIP-graph replay per step — with RCCL the collective and the optimiser are inside
     the captured region (they are stream-ordered kernels), over gloo (a rehearsal) they stay outside and the entry
-    says so.  Afterwards every rank's parameters must be bit-identical (checksum all-gather)."""
+    says so.  Afterwards every rank's parameters must be bit-identical (checksum all-gather).
+    scaling "strong": the ONE `rays`-ray batch of config 5 is cut over the ranks (512 rays each at 8: the step is then
+    bounded by the small-batch rate of one GPU, about 5x at best by construction); "weak": `rays`
+    rays PER RANK (global batch rays x world), the same step, collective and replica check — the form in which a
+    multi-GPU record shows what the all-reduce costs this gradient at full occupancy."""
+    per_rank = rays
+    if scaling == "weak":
+        rays = rays * world
     import torch.distributed as dist
     from nerf_amd import NeRF
     from nerf_amd.loss import mse_and_grad
@@ -400,7 +455,9 @@ def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, sa
     dist.all_gather(gathered, check)
     identical = all(torch.equal(g, gathered[0]) for g in gathered)
     finite = bool(torch.isfinite(torch.cat([p.detach().reshape(-1) for p in model.parameters()])).all())
-    return {"workload": f"BASELINE config 5: {rays}-ray batches x {samples} samples, data-parallel over {world} ranks "
+    return {"scaling": scaling,
+            "workload": f"BASELINE config 5{' (weak form: ' + str(per_rank) + ' rays PER RANK)' if scaling == 'weak' else ''}: "
+                        f"{rays}-ray batches x {samples} samples, data-parallel over {world} ranks "
                         f"({n} rays on rank 0), training forward + HIP backward + one in-place all-reduce of the flat "
                         f"{reduce.numel}-float gradient + one-launch Adam on every rank; {train_precision}; in-kernel Philox draws",
             "rays_per_rank": n, "global_batch": rays, "steps": steps,
@@ -415,7 +472,7 @@ def train_step_dp(dev, rank, world, backend, steps, warmup, fence, rays=4096, sa
             "replicas_identical": identical, "parameters_finite": finite}
 
 
-def legacy_workload_timing(dev, steps=3, warmup=1):
+def legacy_workload_timing(dev, steps=FRAME_STEPS, warmup=1):
     """Second workload: the same 800x800x128 frame through the LEGACY 8 x 256 network of the
     reference's examples/nerf.pth (sin/cos encoding, skip trunk, view branch; 1,261,568 FLOP per sample,
     fp32 MFMA; weights: the reference's trained Lego checkpoint, fixture G9).  Parity unpinned."""
@@ -444,28 +501,24 @@ def legacy_workload_timing(dev, steps=3, warmup=1):
         torch.cuda.synchronize(dev)
         _lib.timing(True)
         _lib.timing_read(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
+        ms = spread(timed_loops(dev, step, steps))
         kernel_ms, launches = _lib.timing_read(reset=True)
         _lib.timing(False)
-        return dt, kernel_ms
+        return ms["median"] * 1e-3, kernel_ms, ms
 
     flop = IMAGE * IMAGE * SAMPLES * LEGACY_FLOP
-    dt, kernel_ms = timed("fp32")
+    dt, kernel_ms, ms = timed("fp32")
     achieved = flop / (kernel_ms * 1e-3) / 1e12
-    dt_h, kernel_ms_h = timed("f16x3")
+    dt_h, kernel_ms_h, ms_h = timed("f16x3")
     achieved_h = flop / (kernel_ms_h * 1e-3) / 1e12
     return {"workload": "legacy 8x256 network (examples/nerf.pth weights), 800x800, 128 samples/ray, "
                         "sin/cos positional encoding, fp32 MFMA; parity unpinned",
             "value": IMAGE * IMAGE * SAMPLES / dt, "unit": "ray-samples/s", "steps": steps,
-            "ms_per_step": dt * 1e3, "kernel_ms": kernel_ms, "flop_per_sample": LEGACY_FLOP,
+            "ms_per_step": dt * 1e3, "ms_per_step_spread": ms, "kernel_ms": kernel_ms, "flop_per_sample": LEGACY_FLOP,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_FP32_MFMA,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_FP32_MFMA},
             "other_precision": {"precision": "f16x3", "value": IMAGE * IMAGE * SAMPLES / dt_h,
-                                "ms_per_step": dt_h * 1e3, "kernel_ms": kernel_ms_h,
+                                "ms_per_step": dt_h * 1e3, "ms_per_step_spread": ms_h, "kernel_ms": kernel_ms_h,
                                 "roofline": {"bound": "mfma", "achieved": achieved_h, "peak": PEAK_TFLOPS_F16_MFMA,
                                              "unit": "TFLOP/s", "frac": achieved_h / PEAK_TFLOPS_F16_MFMA,
                                              "executed_frac": 3 * achieved_h / PEAK_TFLOPS_F16_MFMA}}}
@@ -482,6 +535,8 @@ def baseline_configs(dev):
     cam_o, cam_r = look_at(CAMERA)
     cam_o, cam_r = cam_o.to(dev), cam_r.to(dev)
 
+    last = {}
+
     def timed(fn, steps, warmup=1):
         with torch.no_grad():
             for _ in range(warmup):
@@ -489,18 +544,15 @@ def baseline_configs(dev):
             torch.cuda.synchronize(dev)
             _lib.timing(True)
             _lib.timing_read(reset=True)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / steps
+            last["spread"] = spread(timed_loops(dev, fn, steps))
             kernel_ms, launches = _lib.timing_read(reset=True)
             _lib.timing(False)
-        return dt, kernel_ms, launches // steps
+        return last["spread"]["median"] * 1e-3, kernel_ms, launches // (steps * REPEATS)
 
     def entry(workload, dt, nominal, evaluated, steps, kernel_ms, launches, flop_per_sample=FLOP_PER_SAMPLE):
         tf = evaluated * flop_per_sample / dt / 1e12
-        return {"workload": workload, "steps": steps, "ms_per_step": dt * 1e3, "ray_samples_per_s": nominal / dt,
+        return {"workload": workload, "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_spread": last["spread"],
+                "ray_samples_per_s": nominal / dt,
                 "evaluated_samples": evaluated, "tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TFLOPS_FP32_MFMA,
                 "render_launches_per_step": launches, "avg_render_kernel_ms": kernel_ms}
 
@@ -515,40 +567,40 @@ def baseline_configs(dev):
 
     out = {}
     m = model_for(112.0)
-    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, 100, 100, 112.0, 64), steps=20, warmup=3)
-    out["C2"] = entry("100x100 frame, 64 samples/ray, one launch", dt, 100 * 100 * 64, 100 * 100 * 63, 20, k, n)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, 100, 100, 112.0, 64), steps=SHORT_STEPS, warmup=3)
+    out["C2"] = entry("100x100 frame, 64 samples/ray, one launch", dt, 100 * 100 * 64, 100 * 100 * 63, SHORT_STEPS, k, n)
     m = model_for(448.0)
-    dt, k, n = timed(lambda: m.render_image_hierarchical(cam_o, cam_r, 400, 400, 448.0, 64, 128), steps=3)
+    dt, k, n = timed(lambda: m.render_image_hierarchical(cam_o, cam_r, 400, 400, 448.0, 64, 128), steps=FRAME_STEPS)
     out["C3"] = entry("400x400 frame, 64 coarse + 128 fine samples/ray (coarse render, inverse-CDF resample, "
                       "fine render of the 192-fencepost union); parity unpinned (no reference code)",
-                      dt, 400 * 400 * (64 + 192), 400 * 400 * (63 + 191), 3, k, n)
+                      dt, 400 * 400 * (64 + 192), 400 * 400 * (63 + 191), FRAME_STEPS, k, n)
     m = model_for(FOCAL)
-    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192), steps=3)
-    out["C4"] = entry("800x800 frame, 192 samples/ray, one GPU", dt, IMAGE * IMAGE * 192, IMAGE * IMAGE * 191, 3, k, n)
-    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192, row_begin=300, row_end=400), steps=5)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192), steps=FRAME_STEPS)
+    out["C4"] = entry("800x800 frame, 192 samples/ray, one GPU", dt, IMAGE * IMAGE * 192, IMAGE * IMAGE * 191, FRAME_STEPS, k, n)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, 192, row_begin=300, row_end=400), steps=FRAME_STEPS)
     out["C4_shard"] = entry("rows 300..399 of the 800x800x192 frame: the share of one of 8 GPUs (no collective)",
-                            dt, 100 * IMAGE * 192, 100 * IMAGE * 191, 5, k, n)
+                            dt, 100 * IMAGE * 192, 100 * IMAGE * 191, FRAME_STEPS, k, n)
     m = model_for(FOCAL, scale=3.0)
-    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=3)
+    dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=FRAME_STEPS)
     out["headline_weights_x3"] = entry("the headline 800x800x128 frame with every Linear weight x3 (early "
                                        "saturation: the kernel has no early-out, cost must not change)",
-                                       dt, IMAGE * IMAGE * SAMPLES, IMAGE * IMAGE * (SAMPLES - 1), 3, k, n)
+                                       dt, IMAGE * IMAGE * SAMPLES, IMAGE * IMAGE * (SAMPLES - 1), FRAME_STEPS, k, n)
     # narrow networks at their own cost (nerf/model.py:471-475: hidden_size / encoding_size are constructor keywords):
     # the headline frame through the kernels instantiated for 8 and 4 register tiles per sample; algorithmic FLOP =
     # 2 (3 enc H + 4 H^2 + 54 H) per evaluated sample, against the same fp32 MFMA peak
     for name, hidden, enc in (("narrow_hidden128", 128, 32), ("narrow_hidden64_enc16", 64, 16)):
         m = model_for(FOCAL, hidden_size=hidden, encoding_size=enc)
         flop = 2 * (3 * enc * hidden + 4 * hidden * hidden + 54 * hidden)
-        dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=5)
+        dt, k, n = timed(lambda: m.render_image(cam_o, cam_r, IMAGE, IMAGE, FOCAL, SAMPLES), steps=FRAME_STEPS)
         out[name] = entry(f"the headline 800x800x128 frame, hidden_size={hidden}, encoding_size={enc}: the fp32 kernel "
                           f"instantiated at {16 if hidden > 128 else (8 if hidden > 64 else 4)} register tiles per sample "
                           f"(not zero-padded to 256); {flop} FLOP per sample", dt, IMAGE * IMAGE * SAMPLES,
-                          IMAGE * IMAGE * (SAMPLES - 1), 5, k, n, flop_per_sample=flop)
+                          IMAGE * IMAGE * (SAMPLES - 1), FRAME_STEPS, k, n, flop_per_sample=flop)
         out[name]["flop_per_sample"] = flop
     return out
 
 
-def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, train_precision="fp32"):
+def legacy_train_step_timing(dev, rays=4096, samples=64, steps=SHORT_STEPS, warmup=3, train_precision="fp32"):
     """One optimiser step of the notebook's training loop (examples/example.ipynb cell 8) on the LEGACY 8 x 256
     network, the one BASELINE config 5 / the PSNR target were published on: training forward + HIP backward
     (44 gradients) + fused Adam, 4096 rays x 64 samples, stratified draws, noise std 1.  fp32 MFMA forward and
@@ -573,14 +625,12 @@ def legacy_train_step_timing(dev, rays=4096, samples=64, steps=5, warmup=2, trai
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
+    ms = spread(timed_loops(dev, step, steps))
+    kernels = kernel_split(dev, step)
+    dt = ms["median"] * 1e-3
     return {"workload": f"legacy 8x256 network, {rays} rays x {samples} samples, forward + backward + Adam",
-            "ms_per_step": dt * 1e3, "ray_samples_per_s": rays * samples / dt,
+            "ms_per_step": ms["median"], "ms_per_step_spread": ms, "steps_per_loop": steps, "kernels_ms": kernels,
+            "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": 3 * LEGACY_FLOP * rays * samples / dt / 1e12,
             "arithmetic": ("forward, data gradient and weight gradient on f16 pairs (three f16 MFMAs per product); fp32 "
                            "accumulate" if train_precision == "f16x3" else
@@ -671,6 +721,7 @@ def dry_run(args, rank, world):
         dist.init_process_group("gloo")
     rows = shard_rows(rank, world)
     batch = shard_items(4096, rank, world)
+    weak = shard_items(4096 * world, rank, world)        # the weak form of the training entry: 4096 rays per rank
     params = [torch.nn.Parameter(torch.zeros(304438))]
     params[0].grad = torch.full((304438,), float(rank + 1))
     if world > 1:
@@ -693,9 +744,12 @@ def dry_run(args, rank, world):
             "config": {"workload": "dry run: launch, rendezvous and partitions only; no GPU call, nothing measured",
                        "rays_per_gpu": (rows[1] - rows[0]) * IMAGE, "rendezvous_backend": "gloo" if world > 1 else None,
                        "row_blocks": [b[:2] for b in blocks], "collectives": "none"},
-            "train_step_dp": {"rays_per_rank": batch[1] - batch[0], "global_batch": 4096,
+            "train_step_dp": {"scaling": "strong", "rays_per_rank": batch[1] - batch[0], "global_batch": 4096,
                               "batch_blocks": [b[2:] for b in blocks], "gradient_bytes": 304438 * 4,
-                              "flat_all_reduce_matches_weighted_sum": reduced_ok}}), flush=True)
+                              "flat_all_reduce_matches_weighted_sum": reduced_ok},
+            "train_step_dp_weak": {"scaling": "weak", "rays_per_rank": weak[1] - weak[0], "global_batch": 4096 * world,
+                                   "batch_blocks": [list(shard_items(4096 * world, r, world)) for r in range(world)],
+                                   "gradient_bytes": 304438 * 4}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -845,8 +899,10 @@ def main():
     weak = dp = None
     if distributed and args.scaling == "strong":
         weak = measure("weak", args.steps, args.warmup)
+    dp_weak = None
     if distributed:
         dp = train_step_dp(dev, rank, world, backend, max(args.steps, 10), args.warmup, fence)
+        dp_weak = train_step_dp(dev, rank, world, backend, max(args.steps, 10), args.warmup, fence, scaling="weak")
 
     if rank == 0:
         line = {
@@ -879,6 +935,7 @@ def main():
         }
         if dp is not None:
             line["train_step_dp"] = dp
+            line["train_step_dp_weak"] = dp_weak
         if weak is not None:
             line["weak_scaling"] = {"value": weak["value"], "unit": "ray-samples/s",
                                     "ms_per_step": weak["elapsed"] / args.steps * 1e3,

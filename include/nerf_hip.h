@@ -42,12 +42,13 @@ extern "C" {
  * F16X3, training (forward with saves, data gradient, weight gradient) at 8 / 16 in both; a network of H <= 128
  * therefore costs what a 128-wide one costs, not what the 256-wide one does.  Inside the chosen width (and for
  * encoding_size / num_outputs below the maxima) a network runs zero-padded, which is exact (LayerNorm divides by
- * H; nerf_amd/csrc/nerf_layout.h has the argument).  color_outputs other than 3 is not supported.  256 / 96 / 54
- * for the defaults. */
+ * H; nerf_amd/csrc/nerf_layout.h has the argument).  color_outputs (nerf/model.py:471, :541-542, :591-592, :660) is a
+ * run-time count too, 1 .. 12: `rgb` / `d_rgb` then have that many columns.  256 / 96 / 54 / 3 for the defaults. */
 #define NERF_HIP_HIDDEN 256
 #define NERF_HIP_ENC_INPUTS 96
 #define NERF_HIP_DEFAULT_OUTPUTS 54
 #define NERF_HIP_MAX_OUTPUTS 64
+#define NERF_HIP_MAX_COLORS 12
 #define NERF_HIP_NUM_PARAM_TENSORS 22
 
 #define NERF_HIP_PRECISION_FP32 0
@@ -79,7 +80,7 @@ size_t nerf_hip_packed_bytes(void);
  * backward bound |dL/dy| of layer 0 per sample (the f16 scale of that layer's weight gradient).
  */
 int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t enc_inputs, int32_t num_outputs,
-                          float* packed, void* stream);
+                          int32_t color_outputs, float* packed, void* stream);
 
 /* Where rays come from and what is written; replaces the bodies of
  * NeRF.render_rays (nerf/model.py:596-668) and NeRF.render_image (:670-770). */
@@ -115,8 +116,11 @@ typedef struct NerfHipRenderArgs {
     float base_radius_sq;       /* (1/(sqrt(3)*focal))^2 with the CONSTRUCTOR focal (:546) */
     const float* packed;        /* image written by nerf_hip_pack_weights                  */
     /* --- outputs */
-    float* rgb;                 /* [n_rays,3]  sum_s w_s * sigmoid(color_s)   (model.py:660)*/
-    float* seg;                 /* [n_rays,num_outputs-4] log-probabilities (model.py:661-663) or NULL */
+    float* rgb;                 /* [n_rays,color_outputs]  sum_s w_s * sigmoid(color_s)   (model.py:660); may be NULL on a
+                                   training forward asked for out_raw only (then seg / out_weights NULL too):
+                                   nothing is composited                                   */
+    float* seg;                 /* [n_rays,classes] log-probabilities (model.py:661-663) or NULL; classes =
+                                   num_outputs - 1 - color_outputs                         */
     /* optional per-sample outputs of NeRF.forward (model.py:553-594), any may be NULL      */
     float* out_mean;            /* [n_rays,S-1,3]  Gaussian means (model.py:587)           */
     float* out_cov;             /* [n_rays,S-1,3]  diagonal covariances (debug / parity)   */
@@ -138,13 +142,18 @@ typedef struct NerfHipRenderArgs {
      * F16X3 = every fp32 operand split into an f16 pair, three f16 MFMAs per product with fp32
      *         accumulation (~2^-22 relative per product; same 1e-4 RGB parity bar)            */
     int32_t precision;
-    /* rows of the last Linear = 1 density + 3 color + segmentation classes, 4 .. 64 (54 for the
-     * reference's defaults; must be what nerf_hip_pack_weights was given).  With 4 (no classes) `seg`
+    /* rows of the last Linear = 1 density + color_outputs + segmentation classes, 2 .. 64 (54 for the
+     * reference's defaults; must be what nerf_hip_pack_weights was given).  Without classes `seg`
      * must be NULL.  The legacy-network entry points ignore it. */
     int32_t num_outputs;
     /* hidden_size and 3 * encoding_size of the network (what nerf_hip_pack_weights was given); 0 means the
      * defaults 256 / 96.  The legacy-network entry points ignore them. */
     int32_t hidden, enc_inputs;
+    /* color channels of the network (what nerf_hip_pack_weights was given), 1 .. 12; 0 means the default 3.
+     * `rgb` is [n_rays, color_outputs], `seg` [n_rays, num_outputs - 1 - color_outputs].  The legacy-network
+     * entry points ignore it (their network has three). */
+    int32_t color_outputs;
+    int32_t reserved;           /* set 0: the library derives a per-launch constant into its own copy of the block */
 } NerfHipRenderArgs;
 
 /* Fused forward: rays -> fenceposts -> conical-frustum Gaussians -> integrated positional
@@ -168,8 +177,8 @@ size_t nerf_hip_grad_elements(int32_t hidden, int32_t enc_inputs, int32_t num_ou
  * and d_raw enters the data- and weight-gradient kernels directly. */
 typedef struct NerfHipBackwardArgs {
     NerfHipRenderArgs fwd;
-    const float* d_rgb;         /* [n_rays,3]  dL/d rgb                                   */
-    const float* d_seg;         /* [n_rays,num_outputs-4] dL/d seg or NULL (RGB-only loss) */
+    const float* d_rgb;         /* [n_rays,color_outputs]  dL/d rgb                       */
+    const float* d_seg;         /* [n_rays,classes] dL/d seg or NULL (RGB-only loss)      */
     float* grad;                /* [nerf_hip_grad_elements(hidden, enc_inputs, num_outputs)] written (not accumulated) */
     float* scratch;             /* nerf_hip_backward_scratch_bytes() bytes                 */
     const float* d_raw;         /* [n_rays,S-1,num_outputs] dL/d out_raw, or NULL          */
@@ -305,12 +314,13 @@ int nerf_hip_rng_advance(uint64_t* counter, uint64_t delta, void* stream);
  * (1 / count) * 2 (pred - target), rounded as autograd rounds it.  n_rays == 0 gives loss 0 (an empty shard of a
  * data-parallel batch), not NaN.  One workgroup, a fixed summation order: the loss is reproducible. */
 typedef struct NerfHipMseArgs {
-    const float* pred;          /* [n_rays, stages, 3] */
-    const float* target;        /* [n_rays, 3]         */
+    const float* pred;          /* [n_rays, stages, channels] */
+    const float* target;        /* [n_rays, channels]         */
     int64_t n_rays;
     int32_t stages;
-    float* loss;                /* [1]                 */
-    float* grad;                /* [n_rays, stages, 3] */
+    float* loss;                /* [1]                        */
+    float* grad;                /* [n_rays, stages, channels] */
+    int32_t channels;           /* color_outputs of the network; 0 means 3 */
 } NerfHipMseArgs;
 
 int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream);

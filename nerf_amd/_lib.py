@@ -37,6 +37,7 @@ class RenderArgs(ctypes.Structure):
         ("precision", ctypes.c_int32),
         ("num_outputs", ctypes.c_int32),
         ("hidden", ctypes.c_int32), ("enc_inputs", ctypes.c_int32),
+        ("color_outputs", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -89,7 +90,7 @@ class AdamArgs(ctypes.Structure):
 class MseArgs(ctypes.Structure):
     """Mirror of NerfHipMseArgs (include/nerf_hip.h)."""
     _fields_ = [("pred", _f32p), ("target", _f32p), ("n_rays", ctypes.c_int64), ("stages", ctypes.c_int32),
-                ("loss", _f32p), ("grad", _f32p)]
+                ("loss", _f32p), ("grad", _f32p), ("channels", ctypes.c_int32)]
 
 
 NUM_LEGACY_PARAM_TENSORS = 44
@@ -133,7 +134,7 @@ def lib():
     handle.nerf_hip_packed_bytes.restype = ctypes.c_size_t
     handle.nerf_hip_pack_weights.restype = ctypes.c_int
     handle.nerf_hip_pack_weights.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32,
-                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     handle.nerf_hip_render_forward.restype = ctypes.c_int
     handle.nerf_hip_render_forward.argtypes = [ctypes.POINTER(RenderArgs), ctypes.c_void_p]
     handle.nerf_hip_train_workspace_bytes.restype = ctypes.c_size_t

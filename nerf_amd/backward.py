@@ -100,10 +100,13 @@ class FieldFunction(torch.autograd.Function):
         n_rays, num_samples, device = samples.shape[0], samples.shape[-1], rays_o.device
         ws_bytes = lib.nerf_hip_train_workspace_bytes(n_rays, num_samples)
         workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
-        rgb, seg, mean, raw, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
-                                               t_values=samples, per_sample=True, train_workspace=workspace)
+        # field only: nothing is composited (no rgb / seg / weights tensors, no compositing launch) — the backward
+        # takes dL/d(raw) and needs none of it
+        _, _, mean, raw, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
+                                           t_values=samples, per_sample=True, train_workspace=workspace,
+                                           composite=False)
         ctx.model = model
-        ctx.call = (rays_o, rays_d, samples, rgb, seg)
+        ctx.call = (rays_o, rays_d, samples)
         ctx.workspace = workspace
         ctx.precision = _lib.PRECISIONS[model.train_precision]
         ctx.packed = model._last_packed
@@ -115,15 +118,14 @@ class FieldFunction(torch.autograd.Function):
     def backward(ctx, _d_mean, d_raw):
         lib = _lib.lib()
         model = ctx.model
-        rays_o, rays_d, samples, rgb, seg = ctx.call
+        rays_o, rays_d, samples = ctx.call
         n_rays, num_samples, device = samples.shape[0], samples.shape[-1], rays_o.device
         if d_raw is None:
             return (None,) * (4 + len(ctx.shapes))
         d_raw = d_raw.contiguous()
         args = _lib.BackwardArgs()
         model._fill_args(args.fwd, n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d, t_values=samples,
-                         packed=ctx.packed, rgb=rgb, seg=seg if model.segmentation_outputs > 0 else None,
-                         train_workspace=ctx.workspace, precision=ctx.precision)
+                         packed=ctx.packed, train_workspace=ctx.workspace, precision=ctx.precision)
         grad = torch.empty(lib.nerf_hip_grad_elements(model.hidden_size, model.enc_inputs, model.num_outputs),
                            dtype=torch.float32, device=device)
         scratch = model._scratch(lib.nerf_hip_backward_scratch_bytes(n_rays, num_samples), device)

@@ -76,13 +76,15 @@ __global__ __launch_bounds__(256) void nerf_field_scatter_kernel(const BwdArgs b
     const int64_t tile = sp >> 4;
     const int64_t slot = tile / ba.chunks;
     const int s = (int)(tile - slot * ba.chunks) * 16 + (int)(sp & 15);
-    const int n_out = ba.a.num_outputs;
+    const Shape sh = shape_of(ba.a);
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (slot < ba.a.n_rays && s < ba.intervals) {
-        const float* src = ba.d_raw + (slot * ba.intervals + s) * n_out;
+        const float* src = ba.d_raw + (slot * ba.intervals + s) * sh.n_out;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * q + k < n_out) v[k] = src[4 * q + k];
+        for (int k = 0; k < 4; ++k) {
+            const int row = row_of_slot(4 * q + k, sh);        // slot of the padded tile -> column of d_raw
+            if (row >= 0) v[k] = src[row];
+        }
     }
     *(f32x4*)(ba.a.train_workspace + ba.L.dy5 + sp * kOutPad + 4 * q) = v;
 }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_n8_kernel(const BwdArg
 
             f32x4 xh[16];
             float rstd;
-            // x_hat / 1/std of layer 4 first: 17 loads that fly under the 4 stages of layer 5
+            // x_hat / 1/std of layer 4 first: NT + 1 = 9 loads that fly under the 2 stages of layer 5 (kYoungerL5N8)
             {
                 const float* xrow = ws_rows + ba.L.xhat[4];
                 rstd = (ws_stat + ba.L.rstd[4])[lane_word(j)];
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_n8_kernel(const BwdArg
                     note_max(wmax + 0, rstd * unscale * a.packed[kBoundsOffset], lane);
                     break;
                 }
-                // the next LayerNorm backward's saved tile: 17 loads behind the 16 saves above (1/std first: its
+                // the next LayerNorm backward's saved tile: NT + 1 = 9 loads behind the NT = 8 saves above (kYoungerHiddenN8 = 17; 1/std first: its
                 // address is the one thing here that is not a row offset), all of them younger than the two stages
                 // this layer's loop opens first
                 {
@@ -678,10 +680,10 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
     int so;
     if (which == 0) {          // (row, column) of the tensor -> its place in the full-width slab
         if (L == 0) so = kSlabW0 + (idx / sh.enc_in) * kEncIn + layer0_kernel_column(idx % sh.enc_in, sh.scales());
-        else if (L == 5) so = kSlabW5 + (idx / sh.hidden) * kHidden + idx % sh.hidden;
+        else if (L == 5) so = kSlabW5 + slot_of_row(idx / sh.hidden, sh) * kHidden + idx % sh.hidden;
         else so = kSlabWh + (L - 1) * kHidden * kHidden + (idx / sh.hidden) * kHidden + idx % sh.hidden;
     } else {
-        so = kSlabB + L * kHidden + idx;
+        so = kSlabB + L * kHidden + (L == 5 ? slot_of_row(idx, sh) : idx);
     }
     ba.grad[e] = strided_sum(ba.slabs + so, ba.splits, kSlabFloats);
 }
@@ -714,7 +716,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         return nerf_common::fail(NERF_HIP_EINVAL, "render_backward: grad is null");
     if (!shape_ok(shape_of(a)))
         return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_backward: network shape out of range (hidden 1 .. 256, enc_inputs "
-                                                        "6 .. 96 in steps of 6, num_outputs 4 .. 64)");
+                                                        "6 .. 96 in steps of 6, color_outputs 1 .. 12, num_outputs 1 + color_outputs .. 64)");
     if (a.n_rays == 0)      // empty batch (an empty data-parallel shard): the gradient is zero
         return nerf_common::check_hip(hipMemsetAsync(args->grad, 0, (size_t)grad_elements(shape_of(a)) * sizeof(float),
                                                      (hipStream_t)stream), "render_backward memset");
@@ -730,6 +732,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
 
     BwdArgs ba;
     ba.a = a;
+    derive_slot_constants(ba.a);
     ba.d_rgb = args->d_rgb;
     ba.d_seg = args->d_seg;
     ba.d_raw = args->d_raw;

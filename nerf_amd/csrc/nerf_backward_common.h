@@ -167,10 +167,13 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
     const bool ray_ok = local < a.n_rays;
     if (!ray_ok) local = a.n_rays - 1;
 
-        // upstream gradients of this ray
-        const float g0 = ray_ok ? ba.d_rgb[local * 3 + 0] : 0.f;
-        const float g1 = ray_ok ? ba.d_rgb[local * 3 + 1] : 0.f;
-        const float g2 = ray_ok ? ba.d_rgb[local * 3 + 2] : 0.f;
+        // upstream gradients of this ray: this lane group's color channels 3 g .. 3 g + 2 (nerf_layout.h: color_slot),
+        // zero for channels the network does not have
+        const Shape sh = shape_of(a);
+        const int C = sh.colors, c0 = 3 * g;
+        const float g0 = ray_ok && c0 < C ? ba.d_rgb[local * C + c0] : 0.f;
+        const float g1 = ray_ok && c0 + 1 < C ? ba.d_rgb[local * C + c0 + 1] : 0.f;
+        const float g2 = ray_ok && c0 + 2 < C ? ba.d_rgb[local * C + c0 + 2] : 0.f;
         const bool with_seg = ba.d_seg != nullptr;
 
         float suffix = 0.f;                       // sum_{m in later chunks} q_m w_m
@@ -201,11 +204,12 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                 for (int T = 0; T < 4; ++T) out[T] = next_out[T];
                 if (c > 0) fetch(c - 1);
                 const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
-                // colour: logits on lane group 0 (slots 1..3)
+                // colour: the logits of this lane group's channels in registers y, z, w of tile 0; dL/dw sums over all
+                // channels, i.e. over the four lane groups of the sample (for 3 channels: lane group 0's value + zeros)
                 const float sr = 1.0f / (1.0f + expf(-out[0].y));
                 const float sg = 1.0f / (1.0f + expf(-out[0].z));
                 const float sb = 1.0f / (1.0f + expf(-out[0].w));
-                float q = __shfl((g0 * sr + g1 * sg) + g2 * sb, j);           // dL/dw, colour part
+                float q = group_sum((g0 * sr + g1 * sg) + g2 * sb);           // dL/dw, colour part
                 // segmentation: v_sc = log(w + 1e-10) + log_softmax(x_s)[c]; seg_c = logsumexp_s v_sc
                 float m = 0.f, logz = 0.f, lw = 0.f, srho = 0.f;
                 float gseg[16], oseg[16];         // dL/dseg and forward seg of this lane's slots
@@ -216,10 +220,10 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int n = 16 * T + 4 * g + r;
-                            if (ray_ok && n >= 4 && n < a.num_outputs) {
-                                gseg[4 * T + r] = ba.d_seg[local * (a.num_outputs - 4) + (n - 4)];
-                                oseg[4 * T + r] = a.seg[local * (a.num_outputs - 4) + (n - 4)];
+                            const int row = row_of_slot(16 * T + 4 * g + r, sh);
+                            if (ray_ok && row > C) {
+                                gseg[4 * T + r] = ba.d_seg[local * sh.classes() + (row - 1 - C)];
+                                oseg[4 * T + r] = a.seg[local * sh.classes() + (row - 1 - C)];
                             }
                         }
                     m = -__builtin_inff();
@@ -227,21 +231,21 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r, a.num_outputs)) m = __builtin_fmaxf(m, out[T][r]);
+                            if (is_seg_slot(T, g, r, a)) m = __builtin_fmaxf(m, out[T][r]);
                     m = group_max(m);
                     float z = 0.f;
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r, a.num_outputs)) z += expf(out[T][r] - m);
+                            if (is_seg_slot(T, g, r, a)) z += expf(out[T][r] - m);
                     logz = logf(group_sum(z));
                     lw = logf(w + 1e-10f);
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (is_seg_slot(T, g, r, a.num_outputs)) {
+                            if (is_seg_slot(T, g, r, a)) {
                                 const float rho = expf(lw + ((out[T][r] - m) - logz) - oseg[4 * T + r]);
                                 srho = __builtin_fmaf(gseg[4 * T + r], rho, srho);
                             }
@@ -258,21 +262,18 @@ __device__ __forceinline__ void composite_bwd_body(const NerfHipRenderArgs& a, c
                 for (int T = 0; T < 4; ++T)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int n = 16 * T + 4 * g + r;
                         float v = 0.f;
-                        if (n >= 4 && n < a.num_outputs && with_seg) {
+                        if (with_seg && is_seg_slot(T, g, r, a)) {
                             const float lp = (out[T][r] - m) - logz;
                             const float rho = expf(lw + lp - oseg[4 * T + r]);
                             v = gseg[4 * T + r] * rho - expf(lp) * srho;
                         }
                         dout[T][r] = v;
                     }
-                if (g == 0) {
-                    dout[0].x = dsigma;
-                    dout[0].y = g0 * w * sr * (1.0f - sr);
-                    dout[0].z = g1 * w * sg * (1.0f - sg);
-                    dout[0].w = g2 * w * sb * (1.0f - sb);
-                }
+                if (g == 0) dout[0].x = dsigma;
+                if (c0 < C) dout[0].y = g0 * w * sr * (1.0f - sr);
+                if (c0 + 1 < C) dout[0].z = g1 * w * sg * (1.0f - sg);
+                if (c0 + 2 < C) dout[0].w = g2 * w * sb * (1.0f - sb);
                 if (!ok) {
 #pragma unroll
                     for (int T = 0; T < 4; ++T) dout[T] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -120,7 +120,8 @@ __host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g, int tile_fl
 // they divide their sums by hidden_size, not by the 256 features the kernels carry — the padded ones are exactly
 // zero before normalisation (nerf_layout.h: Shape) — and the second pass of the variance is written so that they add exactly nothing (nerf_fused.h).
 __host__ __device__ inline Shape shape_of(const NerfHipRenderArgs& a) {
-    return Shape{a.hidden > 0 ? a.hidden : kHidden, a.enc_inputs > 0 ? a.enc_inputs : kEncIn, a.num_outputs};
+    return Shape{a.hidden > 0 ? a.hidden : kHidden, a.enc_inputs > 0 ? a.enc_inputs : kEncIn, a.num_outputs,
+                 a.color_outputs > 0 ? a.color_outputs : 3};
 }
 struct NormDivisor {
     float inv_n;                // 1 / hidden_size (features beyond it are padding: exactly 0 before normalisation)
@@ -645,11 +646,21 @@ __device__ __forceinline__ float group_max(float v) {
     return __builtin_fmaxf(a, b);
 }
 
-// Output slot n = 16 T + 4 g + reg of the padded last layer: 0 density, 1..3 color,
-// 4..n_out-1 segmentation classes (4..53 for the reference's 50), the rest padding (nerf/model.py:591-592).
-__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg, int n_out) {
+// Output slot n = 16 T + 4 g + reg of the padded last layer (nerf_layout.h: row_of_slot): 0 density, colors in
+// registers 1..3 of tile 0 (three per lane group), the segmentation classes in the remaining slots up to the
+// network's row count, the rest padding (nerf/model.py:591-592).  Tile 0's class slots come as a 16-bit mask the
+// host derived for the launch (NerfHipRenderArgs.reserved in the library's own copy of the block: class_mask_tile0);
+// beyond tile 0 no color lives, and a slot is a class iff it is below the row count.
+__device__ __forceinline__ bool is_seg_slot(int T, int g, int reg, const NerfHipRenderArgs& a) {
     const int n = 16 * T + 4 * g + reg;
-    return n >= 4 && n < n_out;
+    return T == 0 ? ((a.reserved >> n) & 1) != 0 : n < a.num_outputs;
+}
+// what a launch's own copy of the argument block carries beyond the caller's: the normalised color count and the
+// class mask of output tile 0
+__host__ inline void derive_slot_constants(NerfHipRenderArgs& a) {
+    const Shape s = shape_of(a);
+    a.color_outputs = s.colors;
+    a.reserved = class_mask_tile0(s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -887,7 +898,8 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
     acc.carry = acc.carry * __shfl(prod, (lane & 48) | 15);
     if (kSave && g == 0) *(f32x4*)comp = f32x4{alpha, t_excl, dist, dens};
 
-    // RGB: valid on lane group 0, harmless elsewhere
+    // colors: registers y, z, w of tile 0 are channels 3 g, 3 g + 1, 3 g + 2 of this lane group (nerf_layout.h:
+    // color_slot) — all of them for the reference's 3 channels on lane group 0, harmless where the network has none
     const float cr = w * (1.0f / (1.0f + expf(-out[0].y)));
     const float cg = w * (1.0f / (1.0f + expf(-out[0].z)));
     const float cb = w * (1.0f / (1.0f + expf(-out[0].w)));
@@ -902,14 +914,14 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r, a.num_outputs)) m = __builtin_fmaxf(m, out[T][r]);
+                if (is_seg_slot(T, g, r, a)) m = __builtin_fmaxf(m, out[T][r]);
         m = group_max(m);
         float z = 0.f;
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r, a.num_outputs)) z += exp_fast(out[T][r] - m);
+                if (is_seg_slot(T, g, r, a)) z += exp_fast(out[T][r] - m);
         z = group_sum(z);
         const float logz = logf(z);
         const float lw = logf(w + 1e-10f);
@@ -939,20 +951,29 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
 template <bool kSeg = true>
 __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t local, bool ray_ok, int lane,
                                           const RayAccum& acc) {
-    // lane 0 stores the three sums (a per-lane select of acc.rgb0/1/2 by lane id makes the compiler
-    // index the accumulator struct dynamically, which pins it to a scratch-memory stack object that
-    // is then re-written every chunk)
-    if (ray_ok && lane == 0) {
-        a.rgb[local * 3 + 0] = acc.rgb0;
-        a.rgb[local * 3 + 1] = acc.rgb1;
-        a.rgb[local * 3 + 2] = acc.rgb2;
+    // lane 0 of a lane group stores its three sums (a per-lane select of acc.rgb0/1/2 by lane id makes the compiler
+    // index the accumulator struct dynamically, which pins it to a scratch-memory stack object that is then
+    // re-written every chunk): channels 3 g .. 3 g + 2, those the network has
+    if (!kSeg) {                 // the legacy network: three channels, lane group 0's sums (its kernels' code does not move)
+        if (ray_ok && lane == 0) {
+            a.rgb[local * 3 + 0] = acc.rgb0;
+            a.rgb[local * 3 + 1] = acc.rgb1;
+            a.rgb[local * 3 + 2] = acc.rgb2;
+        }
+    } else if (ray_ok && (lane & 15) == 0) {
+        const int C = a.color_outputs, c0 = 3 * (lane >> 4);
+        if (c0 < C) a.rgb[local * C + c0] = acc.rgb0;
+        if (c0 + 1 < C) a.rgb[local * C + c0 + 1] = acc.rgb1;
+        if (c0 + 2 < C) a.rgb[local * C + c0 + 2] = acc.rgb2;
     }
     if (kSeg && a.seg != nullptr) {
         // the wave's 64 lanes cover n = 0..63 once: the class values leave in one store
         const int j = lane & 15, g = lane >> 4;
         const float mine = acc.seg_m + logf(acc.seg_s);
         const int n = 16 * (j >> 2) + 4 * g + (j & 3);
-        if (ray_ok && n >= 4 && n < a.num_outputs) a.seg[local * (a.num_outputs - 4) + (n - 4)] = mine;
+        const Shape sh = shape_of(a);
+        const int row = row_of_slot(n, sh);
+        if (ray_ok && row > sh.colors) a.seg[local * sh.classes() + (row - 1 - sh.colors)] = mine;
     }
 }
 

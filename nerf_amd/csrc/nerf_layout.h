@@ -27,8 +27,9 @@ namespace nerf_layout {
 constexpr int kHidden = 256;
 constexpr int kEncIn = 96;
 constexpr int kOutPad = 64;      // the last layer's outputs padded to four 16-row tiles; the number in use
-                                 // (1 density + 3 color + segmentation classes, <= 64) is a launch argument
-constexpr int kMinOutputs = 4;   // density + color, no segmentation classes
+                                 // (1 density + color_outputs + segmentation classes, <= 64) is a launch argument
+constexpr int kMinOutputs = 2;   // density + one color channel, no segmentation classes
+constexpr int kMaxColors = 12;   // color channels (run-time count): three per lane group of output tile 0
 
 constexpr int kStageBytes = 16384;
 constexpr int kStageFloats = kStageBytes / 4;
@@ -143,12 +144,68 @@ __host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 :
 struct Shape {
     int hidden;                 // H
     int enc_in;                 // 6 S: inputs of layer 0, [sin: scale-major x coord-minor | shifted: same] (model.py:158-163)
-    int n_out;                  // rows of the last Linear
+    int n_out;                  // rows of the last Linear = 1 + colors + segmentation classes
+    int colors = 3;             // color_outputs (nerf/model.py:471, :541-542, :591-592, :660)
     __host__ __device__ int scales() const { return enc_in / 6; }
+    __host__ __device__ int classes() const { return n_out - 1 - colors; }
 };
 __host__ __device__ inline bool shape_ok(const Shape& s) {
     return s.hidden >= 1 && s.hidden <= kHidden && s.enc_in >= 6 && s.enc_in <= kEncIn && s.enc_in % 6 == 0 &&
-           s.n_out >= kMinOutputs && s.n_out <= kOutPad;
+           s.colors >= 1 && s.colors <= kMaxColors && s.n_out >= 1 + s.colors && s.n_out <= kOutPad;
+}
+
+// ROWS of the last Linear (state_dict order: density | colors | classes, nerf/model.py:591-592) against SLOTS of the
+// kernels' padded 64-row output tile (slot n = 16 T + 4 g + r lives in register r of tile T of lane group g).
+// Compositing keeps THREE running color sums per lane, registers y, z, w of tile 0 — so color channel c sits at slot
+// 4 (c / 3) + 1 + c % 3: lane group g holds channels 3 g .. 3 g + 2, up to 12 of them, at no cost to the kernels
+// (the sums were always computed on all four lane groups; only lane group 0's were stored).  Density is slot 0; the
+// classes fill the remaining slots in increasing order.  For the reference's 3 channels this is the identity map
+// (density 0, colors 1..3, classes 4..), which is what every fixture and profile of rounds 1-5 ran with.
+__host__ __device__ inline int color_slot(int c) { return 4 * (c / 3) + 1 + c % 3; }
+__host__ __device__ inline bool is_color_slot(int n, int colors) {
+    return n < 16 && (n & 3) != 0 && 3 * (n >> 2) + (n & 3) - 1 < colors;
+}
+__host__ __device__ inline int colors_below(int n, int colors) {      // color slots among 0 .. n - 1
+    if (n >= 16) return colors;
+    const int g = n >> 2, r = n & 3;
+    const int full = 3 * g < colors ? 3 * g : colors;                 // lane groups below g
+    const int left = colors - 3 * g > 0 ? colors - 3 * g : 0, mine = r > 1 ? r - 1 : 0;
+    return full + (mine < left ? mine : left);
+}
+// row of the last Linear held by slot n, or -1 for a padding slot
+__host__ __device__ inline int row_of_slot(int n, int colors, int n_out) {
+    if (n == 0) return 0;
+    if (is_color_slot(n, colors)) return 1 + 3 * (n >> 2) + (n & 3) - 1;
+    const int row = 1 + colors + (n - 1 - colors_below(n, colors));
+    return row < n_out ? row : -1;
+}
+__host__ __device__ inline int row_of_slot(int n, const Shape& s) { return row_of_slot(n, s.colors, s.n_out); }
+// the same for register r of output tile 0 on lane group g (slot 4 g + r), in the few operations a kernel that is
+// short of registers can afford: the group holds `left` = clamp(colors - 3 g, 0, 3) color channels in registers
+// 1 .. left, its other slots are classes counted from `base` = the row of the group's register 0
+__host__ __device__ inline int row_of_tile0(int g, int r, int colors, int n_out) {
+    const int c0 = 3 * g, below = c0 < colors ? c0 : colors;
+    const int left = colors - below;                       // (> 3 is as good as 3: r - 1 <= 2)
+    const int base = colors + 4 * g - below;
+    const int row = r == 0 ? (g == 0 ? 0 : base) : (r - 1 < left ? c0 + r : base + r - (left < 3 ? left : 3));
+    return row < n_out ? row : -1;
+}
+__host__ __device__ inline int slot_of_row(int row, const Shape& s) {
+    if (row == 0) return 0;
+    if (row <= s.colors) return color_slot(row - 1);
+    for (int n = 1; n < kOutPad; ++n)
+        if (!is_color_slot(n, s.colors) && 1 + s.colors + (n - 1 - colors_below(n, s.colors)) == row) return n;
+    return -1;
+}
+// bit n (n < 16) = slot n of output tile 0 holds a segmentation class (slots >= 16: class iff n < n_out, no color
+// lives there): computed by the host per launch, tested per element by the compositing code
+__host__ __device__ inline int class_mask_tile0(const Shape& s) {
+    int m = 0;
+    for (int n = 1; n < 16; ++n) {
+        const int row = row_of_slot(n, s);
+        if (row > s.colors) m |= 1 << n;
+    }
+    return m;
 }
 
 // flat gradient vector: the 22 tensors in state_dict order, PyTorch layouts

@@ -835,6 +835,8 @@ int nerf_hip_legacy_render_forward(const NerfHipLegacyArgs* args, void* stream) 
 
     LegacyKernelArgs ka;
     ka.l = *args;
+    ka.l.render.color_outputs = 3;        // the shared compositing code stores / reads this many channels per ray
+    ka.l.render.reserved = 0;
     ka.chunks = (a.num_samples + kSamplesPerWave - 1) / kSamplesPerWave;
     ka.save = make_legacy_train_layout(a.n_rays, ka.chunks);
     // inference: one ray per wave; training: one (padded ray, chunk) item per wave

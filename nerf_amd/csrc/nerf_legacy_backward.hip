@@ -552,6 +552,8 @@ int nerf_hip_legacy_render_backward(const NerfHipLegacyBackwardArgs* args, void*
 
     LBwdArgs ba;
     ba.a = a;
+    ba.a.color_outputs = 3;             // (the shared compositing backward reads d_rgb with this many columns)
+    ba.a.reserved = 0;
     ba.d_rgb = args->d_rgb;
     ba.samples = a.num_samples;
     ba.chunks = (a.num_samples + kSamplesPerWave - 1) / kSamplesPerWave;

@@ -554,12 +554,19 @@ __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void
             if (kPerSample && ray_ok && ok) {
                 const int64_t smp = local * P + s;
                 if (a.out_raw != nullptr) {
+                    // (the lane group behind an optimisation barrier: the columns of tile 0 depend on nothing but g
+                    //  and the launch's constants, and hoisted out of the ray loop they live across the MLP as spills)
+                    int gq = g;
+                    asm volatile("" : "+v"(gq));
 #pragma unroll
                     for (int T = 0; T < 4; ++T)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            // (slot of the padded tile -> column: beyond tile 0 they coincide, nerf_layout.h)
                             const int n = 16 * T + 4 * g + r;
-                            if (n < a.num_outputs) a.out_raw[smp * a.num_outputs + n] = out[T][r];
+                            const int row = T == 0 ? row_of_tile0(gq, r, a.color_outputs, a.num_outputs) : (n < a.num_outputs ? n : -1);
+                            if (row >= 0) a.out_raw[smp * a.num_outputs + row] = out[T][r];
+                            if (T == 0) asm volatile("" : "+v"(gq) :: "memory");     // one column's address at a time
                         }
                 }
                 if (g == 0) {
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(256) void nerf_field_outputs_kernel(const KernelArg
     const int P = ka.intervals, n_out = a.num_outputs;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.n_rays * P * n_out) return;
-    const int n = (int)(e % n_out);
+    const int row = (int)(e % n_out), n = slot_of_row(row, shape_of(a));     // output row -> its slot of the padded tile
     const int64_t smp = e / n_out;
     const int64_t local = smp / P;
     const int s = (int)(smp - local * P);
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(256) void nerf_field_outputs_kernel(const KernelArg
     const int j = s & 15;
     if (a.out_raw != nullptr)
         a.out_raw[e] = a.train_workspace[ka.save.out + tile * 1024 + (n >> 4) * 256 + (((n & 15) >> 2) * 16 + j) * 4 + (n & 3)];
-    if (n == 0 && (a.out_mean != nullptr || a.out_cov != nullptr)) {
+    if (row == 0 && (a.out_mean != nullptr || a.out_cov != nullptr)) {
         const Ray ray = load_ray(a, local);
         const Gaussian gm = frustum(ray, fencepost(a, local, s), fencepost(a, local, s + 1), a.base_radius_sq);
 #pragma unroll
@@ -632,7 +639,9 @@ __global__ __launch_bounds__(256) void nerf_field_outputs_kernel(const KernelArg
 struct PackArgs {
     const float* p[NERF_HIP_NUM_PARAM_TENSORS];
     float* packed;
-    int32_t n_out;              // rows of the last Linear (1 + 3 + segmentation classes); padded to 64 with zeros
+    int32_t n_out;              // rows of the last Linear (1 + colors + segmentation classes); padded to 64 with zeros
+    int32_t colors;             // color channels: which slot of the padded tile a row lands in (nerf_layout.h: row_of_slot)
+    __device__ __forceinline__ int row5(int slot) const { return row_of_slot(slot, Shape{hidden, enc_in, n_out, colors}); }
     int32_t hidden, enc_in;     // H and 6 x scales of the source tensors; the images are zero beyond them (nerf_layout.h)
     // element (out, in) of the source matrices, 0 in the padding: layer 0 by kernel slot (t, g, r), the hidden
     // layers L = 1..4, the last layer; element f of a per-feature vector (bias / gamma / beta: tensor index)
@@ -644,7 +653,8 @@ struct PackArgs {
         return out < hidden && in < hidden ? p[4 * L][out * hidden + in] : 0.f;
     }
     __device__ __forceinline__ float w5(int out, int in) const {
-        return out < n_out && in < hidden ? p[20][out * hidden + in] : 0.f;
+        const int row = row5(out);                  // `out`: slot of the padded output tile
+        return row >= 0 && in < hidden ? p[20][row * hidden + in] : 0.f;
     }
     __device__ __forceinline__ float vec(int tensor, int f) const { return f < hidden ? p[tensor][f] : 0.f; }
 };
@@ -853,7 +863,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int q = i - 5 * kSmallPerLayer;
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
             const int n = 16 * T + 4 * g + reg;
-            if (n < pa.n_out) v = pa.p[21][n] * sb;
+            if (pa.row5(n) >= 0) v = pa.p[21][pa.row5(n)] * sb;
         }
     } else if (e >= kHBlobOffset) {
         // split-precision image (nerf_layout.h): this float slot carries two f16 of one slab
@@ -922,7 +932,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int q = i - 5 * kSmallPerLayer;                   // last bias [g][T(4)][reg]
             const int g = q / 16, T = (q % 16) / 4, reg = q & 3;
             const int n = 16 * T + 4 * g + reg;
-            if (n < pa.n_out) v = pa.p[21][n];
+            if (pa.row5(n) >= 0) v = pa.p[21][pa.row5(n)];
         }
     }
     pa.packed[e] = v;
@@ -950,19 +960,22 @@ size_t nerf_hip_train_workspace_bytes(int64_t n_rays, int32_t num_samples) {
 }
 
 size_t nerf_hip_grad_elements(int32_t hidden, int32_t enc_inputs, int32_t num_outputs) {
-    const Shape s{hidden, enc_inputs, num_outputs};
+    const Shape s{hidden, enc_inputs, num_outputs, 1};       // (the count does not depend on how the rows split)
     return shape_ok(s) ? (size_t)grad_elements(s) : 0;
 }
 
 int nerf_hip_pack_weights(const float* const* params, int32_t hidden, int32_t enc_inputs, int32_t num_outputs,
-                          float* packed, void* stream) {
+                          int32_t color_outputs, float* packed, void* stream) {
     if (params == nullptr || packed == nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "pack_weights: null pointer");
-    if (!shape_ok(Shape{hidden, enc_inputs, num_outputs}))
+    if (color_outputs == 0) color_outputs = 3;
+    if (!shape_ok(Shape{hidden, enc_inputs, num_outputs, color_outputs}))
         return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "pack_weights: hidden must be 1 .. 256, enc_inputs a multiple of 6 in 6 .. 96, "
-                                                        "num_outputs 4 .. 64 (1 density + 3 color + segmentation classes)");
+                                                        "color_outputs 1 .. 12, num_outputs 1 + color_outputs .. 64 (1 density + "
+                                                        "color + segmentation classes)");
     PackArgs pa;
     pa.n_out = num_outputs;
+    pa.colors = color_outputs;
     pa.hidden = hidden;
     pa.enc_in = enc_inputs;
     for (int i = 0; i < NERF_HIP_NUM_PARAM_TENSORS; ++i) {
@@ -982,12 +995,17 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (a.n_rays == 0) return NERF_HIP_OK;
     if (a.n_rays < 0 || a.num_samples < 2 || a.num_samples > 4096)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: n_rays / num_samples out of range");
-    if (a.packed == nullptr || a.rgb == nullptr || (a.t_table == nullptr && a.t_values == nullptr))
+    // rgb may be NULL on a TRAINING forward that is asked for the per-sample outputs only (a differentiable
+    // NeRF.forward, model.py:553-594: nothing is composited, its backward takes d_raw)
+    const bool field_only = a.rgb == nullptr && a.train_workspace != nullptr && a.out_raw != nullptr &&
+                            a.seg == nullptr && a.out_weights == nullptr;
+    if (a.packed == nullptr || (a.rgb == nullptr && !field_only) || (a.t_table == nullptr && a.t_values == nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: packed / rgb / t_table is null");
     if (!shape_ok(shape_of(a)))
         return nerf_common::fail(NERF_HIP_EUNSUPPORTED, "render_forward: hidden must be 1 .. 256, enc_inputs a multiple of 6 in 6 .. 96, "
-                                                        "num_outputs 4 .. 64 (1 density + 3 color + segmentation classes)");
-    if (a.num_outputs == kMinOutputs && a.seg != nullptr)
+                                                        "color_outputs 1 .. 12, num_outputs 1 + color_outputs .. 64 (1 density + "
+                                                        "color + segmentation classes)");
+    if (shape_of(a).classes() == 0 && a.seg != nullptr)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: seg given but the network has no segmentation classes");
     const bool arrays = a.rays_o != nullptr && a.rays_d != nullptr;
     const bool cameras = a.camera_o != nullptr && a.camera_r != nullptr && a.image_h > 0 &&
@@ -999,6 +1017,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
 
     KernelArgs ka;
     ka.a = a;
+    derive_slot_constants(ka.a);
     ka.intervals = a.num_samples - 1;
     ka.chunks = (ka.intervals + kSamplesPerWave - 1) / kSamplesPerWave;
     const bool train = a.train_workspace != nullptr;
@@ -1028,8 +1047,9 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
          {nerf_render_fwd_kernel<false, true, false>, nerf_render_fwd_kernel<false, true, true>}},
         {{nerf_render_fwd_kernel<true, false, false>, nullptr},
          {nerf_render_fwd_kernel<true, true, false>, nullptr}}};
-    // narrow networks at their own cost (fp32 arithmetic): inference [NT 8 | 4][per_sample], training forward at 8;
-    // split-precision launches run a narrow network zero-padded in the full-width kernels
+    // narrow networks at their own cost: fp32 inference [NT 8 | 4][per_sample]; split-precision inference at 8
+    // (narrow_half: a network of hidden_size <= 64 runs zero-padded inside it); training forward at 8 in either
+    // arithmetic (narrow_train[half])
     static const Kernel narrow[2][2] = {
         {nerf_render_fwd_kernel<false, false, false, 8>, nerf_render_fwd_kernel<false, false, true, 8>},
         {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
@@ -1062,7 +1082,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     if (train) {
         nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_FORWARD);
         const int64_t blocks = (a.n_rays + kWavesPerWg - 1) / kWavesPerWg;
-        hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
+        if (!field_only) hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ka);
         if (a.out_raw != nullptr || a.out_mean != nullptr || a.out_cov != nullptr) {
             const int64_t elems = a.n_rays * ka.intervals * a.num_outputs;
             hipLaunchKernelGGL(nerf_field_outputs_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, ka);

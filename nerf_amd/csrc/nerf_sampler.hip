@@ -201,12 +201,13 @@ __global__ __launch_bounds__(1024) void nerf_mse_kernel(const MseKernelArgs ka) 
 #pragma clang fp contract(off)
     __shared__ float part[16];
     const NerfHipMseArgs& a = ka.a;
-    const int64_t per_ray = (int64_t)a.stages * 3, count = a.n_rays * per_ray;
+    const int ch = a.channels > 0 ? a.channels : 3;
+    const int64_t per_ray = (int64_t)a.stages * ch, count = a.n_rays * per_ray;
     const float inv = 1.0f / (float)(count > 0 ? count : 1);      // autograd: d loss / d sum = 1 / count ...
     float acc = 0.f;
     for (int64_t e = threadIdx.x; e < count; e += 1024) {
         // element e = (ray, stage, channel): the target's is (ray, channel); one stage: the same index
-        const int64_t te = a.stages == 1 ? e : (e / per_ray) * 3 + (e % 3);
+        const int64_t te = a.stages == 1 ? e : (e / per_ray) * ch + (e % ch);
         const float x = a.pred[e] - a.target[te];
         acc += x * x;
         a.grad[e] = inv * (2.0f * x);                              // ... times d x^2 / d x = 2 x, one rounding
@@ -256,7 +257,7 @@ extern "C" int nerf_hip_rng_advance(uint64_t* counter, uint64_t delta, void* str
 extern "C" int nerf_hip_mse_loss(const NerfHipMseArgs* args, void* stream) {
     if (args == nullptr) return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null args");
     const NerfHipMseArgs& a = *args;
-    if (a.n_rays < 0 || a.stages < 1 || a.loss == nullptr)
+    if (a.n_rays < 0 || a.stages < 1 || a.loss == nullptr || a.channels < 0 || a.channels > NERF_HIP_MAX_COLORS)
         return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: n_rays / stages / loss pointer out of range");
     if (a.n_rays > 0 && (a.pred == nullptr || a.target == nullptr || a.grad == nullptr))
         return nerf_common::fail(NERF_HIP_EINVAL, "mse_loss: null tensor");

@@ -15,18 +15,20 @@ from . import _lib
 
 
 def _check(pred, target):
-    if (pred.dim() != 3 or pred.shape[-1] != 3 or target.shape != (pred.shape[0], 3) or not pred.is_cuda
-            or pred.dtype != torch.float32 or target.dtype != torch.float32 or target.device != pred.device):
-        raise ValueError("nerf_amd.loss.mse: pred [N, stages, 3] and target [N, 3], float32, on one ROCm device")
+    if (pred.dim() != 3 or not 1 <= pred.shape[-1] <= 12 or target.shape != (pred.shape[0], pred.shape[-1])
+            or not pred.is_cuda or pred.dtype != torch.float32 or target.dtype != torch.float32
+            or target.device != pred.device):
+        raise ValueError("nerf_amd.loss.mse: pred [N, stages, C] and target [N, C] (C = the network's color_outputs, "
+                         "1 .. 12), float32, on one ROCm device")
 
 
 def _launch(pred, target):
-    """(loss [], d loss / d pred) of contiguous ``pred`` [N, stages, 3] against ``target`` [N, 3]: one launch."""
+    """(loss [], d loss / d pred) of contiguous ``pred`` [N, stages, C] against ``target`` [N, C]: one launch."""
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     grad = torch.empty_like(pred)
     args = _lib.MseArgs()
     args.pred, args.target = _lib.ptr(pred), _lib.ptr(target)
-    args.n_rays, args.stages = pred.shape[0], pred.shape[1]
+    args.n_rays, args.stages, args.channels = pred.shape[0], pred.shape[1], pred.shape[2]
     args.loss, args.grad = _lib.ptr(loss), _lib.ptr(grad)
     with torch.cuda.device(pred.device):
         stream = torch.cuda.current_stream(pred.device).cuda_stream
@@ -48,7 +50,7 @@ class _MseFunction(torch.autograd.Function):
 
 
 def mse(pred, target):
-    """mean((pred - target[:, None, :]) ** 2) for pred [N, stages, 3] (or [N, 3]) and target [N, 3], float32 on a
+    """mean((pred - target[:, None, :]) ** 2) for pred [N, stages, C] (or [N, C]) and target [N, C], float32 on a
     ROCm device; differentiable with respect to ``pred``."""
     if pred.dim() == 2:
         return mse(pred.unsqueeze(1), target)

@@ -252,16 +252,16 @@ class NeRF(nn.Module):
         return 3 * self.encoding_size
 
     def _check_shape(self):
-        """hidden_size (<= 256), encoding_size (even, <= 32) and the number of segmentation classes (<= 60) are
-        run-time arguments of the kernels, which exist at 16 / 8 / 4 register tiles per sample: a launch runs at the
-        smallest width that holds hidden_size (a narrow network at its own cost) and zero-padded inside it, which is
-        exact (nerf_amd/csrc/nerf_layout.h: Shape, Narrow).  Three color channels are compiled in (the reference's
-        scripts never use another count)."""
-        if self.color_outputs != 3 or not 1 <= self.hidden_size <= 256 or self.encoding_size % 2 != 0 or \
-                not 2 <= self.encoding_size <= 32 or not 0 <= self.segmentation_outputs <= 60:
+        """hidden_size (<= 256), encoding_size (even, <= 32), color_outputs (1 .. 12) and the number of segmentation
+        classes (1 + colors + classes <= 64: the padded output tile) are run-time arguments of the kernels, which exist
+        at 16 / 8 / 4 register tiles per sample: a launch runs at the smallest width that holds hidden_size (a narrow
+        network at its own cost) and zero-padded inside it, which is exact (nerf_amd/csrc/nerf_layout.h: Shape, Narrow;
+        color channels: row_of_slot)."""
+        if not 1 <= self.color_outputs <= 12 or not 1 <= self.hidden_size <= 256 or self.encoding_size % 2 != 0 or \
+                not 2 <= self.encoding_size <= 32 or self.segmentation_outputs < 0 or self.num_outputs > 64:
             raise NotImplementedError(
-                "libnerf_hip takes 1 <= hidden_size <= 256, an even encoding_size in 2 .. 32, color_outputs=3 and "
-                "0 <= segmentation_outputs <= 60 (the reference's defaults: 256 / 32 / 3 / 50)")
+                "libnerf_hip takes 1 <= hidden_size <= 256, an even encoding_size in 2 .. 32, 1 <= color_outputs <= 12 "
+                "and 1 + color_outputs + segmentation_outputs <= 64 (the reference's defaults: 256 / 32 / 3 / 50)")
 
     def _param_list(self):
         heads = self.prediction_heads
@@ -290,7 +290,8 @@ class NeRF(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.nerf_hip_pack_weights(ptrs, self.hidden_size, self.enc_inputs, self.num_outputs,
-                                                 _lib.ptr(packed), ctypes.c_void_p(stream)), "nerf_hip_pack_weights")
+                                                 self.color_outputs, _lib.ptr(packed), ctypes.c_void_p(stream)),
+                       "nerf_hip_pack_weights")
         if not fresh:
             self._packed = packed
         self._packed_key = tuple((p.data_ptr(), p._version) for p in params)
@@ -373,7 +374,7 @@ class NeRF(nn.Module):
         args.out_mean, args.out_cov, args.out_t = _lib.ptr(mean), _lib.ptr(cov), _lib.ptr(out_t)
         args.out_raw, args.out_weights = _lib.ptr(raw), _lib.ptr(weights)
         args.train_workspace = _lib.ptr(train_workspace)
-        args.num_outputs = self.num_outputs
+        args.num_outputs, args.color_outputs = self.num_outputs, self.color_outputs
         args.hidden, args.enc_inputs = self.hidden_size, self.enc_inputs
         if precision is not None:
             args.precision = precision
@@ -395,7 +396,7 @@ class NeRF(nn.Module):
     def _launch(self, n_rays, num_samples, device, *, rays_o=None, rays_d=None, cameras=None,
                 ray_begin=0, t_values=None, u=None, noise=None, density_noise_std=0.0, rng_mode=0,
                 want_seg=True, per_sample=False, rgb=None, seg=None, rng_state=None, rng_counter=None,
-                train_workspace=None, want_weights=False, cov=None, out_t=None):
+                train_workspace=None, want_weights=False, cov=None, out_t=None, composite=True):
         """``rng_state`` None with ``rng_mode``: the module's own launch sequence (rank bits + the device counter,
         advanced behind the launch); an explicit state is used as it is (reproducible draws), plus
         ``rng_counter`` if the caller passes one (the training forward: its own sequence state, kept for the
@@ -403,8 +404,10 @@ class NeRF(nn.Module):
         lib = _lib.lib()
         packed = self.packed_parameters(fresh=train_workspace is not None)
         P = num_samples - 1
-        if rgb is None:
-            rgb = torch.empty(n_rays, 3, dtype=torch.float32, device=device)
+        if not composite:                               # a training forward for the per-sample outputs only
+            want_seg = False
+        elif rgb is None:
+            rgb = torch.empty(n_rays, self.color_outputs, dtype=torch.float32, device=device)
         if seg is None and want_seg:
             seg = torch.empty(n_rays, self.segmentation_outputs, dtype=torch.float32, device=device)
         if self.segmentation_outputs == 0:
@@ -413,7 +416,8 @@ class NeRF(nn.Module):
         if per_sample:
             mean = torch.empty(n_rays, P, 3, dtype=torch.float32, device=device)
             raw = torch.empty(n_rays, P, self.num_outputs, dtype=torch.float32, device=device)
-            weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
+            if composite:
+                weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         elif want_weights:
             weights = torch.empty(n_rays, P, dtype=torch.float32, device=device)
         if rng_mode and rng_state is None:
@@ -483,9 +487,18 @@ class NeRF(nn.Module):
         density [N,S-1,1], color [N,S-1,3], segmentation [N,S-1,50])  (nerf/model.py:553-594).
         ``states_*`` are accepted and ignored, as in the reference.  Like the reference's it is differentiable
         w.r.t. the parameters when gradients are enabled (a loss on density / color / segmentation trains the
-        network: nerf_amd/backward.py FieldFunction); under ``torch.no_grad()`` it is the plain inference launch."""
+        network: nerf_amd/backward.py FieldFunction); under ``torch.no_grad()`` it is the plain inference launch.
+        Arithmetic: the differentiable call is a TRAINING forward and runs in ``self.train_precision`` (its backward
+        must match it), the no_grad call in ``self.precision``; with the two set differently the same inputs give
+        values that differ by the arithmetics' distance (~1e-6).  NOT differentiable w.r.t. ``rays_o`` /
+        ``rays_d`` / ``samples`` (the reference's autograd reaches them; its scripts never ask): they are detached,
+        with a warning when one of them requires grad."""
         _require_device(rays_o, "rays_o"), _require_device(rays_d, "rays_d")
         _require_device(samples, "samples")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (rays_o, rays_d, samples)):
+            import warnings
+            warnings.warn("nerf_amd.NeRF.forward is differentiable w.r.t. the parameters only: rays_o / rays_d / "
+                          "samples are detached (no gradient reaches them)", stacklevel=2)
         n_rays, num_samples = samples.shape[0], samples.shape[-1]
         o, d, t = rays_o.detach().contiguous(), rays_d.detach().contiguous(), samples.detach().contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

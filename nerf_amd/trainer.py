@@ -183,7 +183,7 @@ class Trainer:
                                           u=u, noise=noise)
         pixels, _ = self.model.render_rays(rays_o, rays_d, self.num_samples, randomly_sample=True,
                                            density_noise_std=self.density_noise_std, u=u, noise=noise)
-        return pixels.view(-1, 3)                         # the single stage (train_conditional_nerf.py:132); a view:
+        return pixels.view(pixels.shape[0], -1)           # the single stage (train_conditional_nerf.py:132); a view:
                                                           # its backward launches nothing (a select would: zeros + copy)
 
     @staticmethod

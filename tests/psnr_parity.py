@@ -10,10 +10,10 @@ tests/test_gpu_psnr_parity.py imports its pieces for a 300-step version.
 From ONE seed (initial parameters, per-step ray indices, stratified draws ``u`` and density noise — all CAPTURED on
 the host and fed to every run) it trains
 
-  cpu_mt / cpu_1t  the oracle (the reference's ATen ops + autograd, oracle/nerf_oracle.py) with torch Adam on the host,
-                 on 14 threads (the box grants 16 CPUs; the 1-thread run and this process take the other two) and on
-                 1 thread: the SAME algorithm under two summation orders — the noise floor any 0.01 dB statement has
-                 to be read against (a training trajectory amplifies rounding differences);
+  cpu_mt / cpu_4t / cpu_2t / cpu_1t  the oracle (the reference's ATen ops + autograd, oracle/nerf_oracle.py) with
+                 torch Adam on the host, on 8, 4, 2 and 1 threads: the SAME algorithm under four summation orders —
+                 six pairs whose PSNR differences are the noise floor any 0.01 dB statement has to be read against
+                 (a training trajectory amplifies rounding differences exponentially until they saturate);
   hip_fp32       nerf_amd.trainer.Trainer, reference arithmetic, eager steps;
   hip_f16x3      the same in split-precision arithmetic;
   hip_f16x3_graph  the same, every step one HIP-graph replay (the captured draws enter as static inputs);
@@ -138,7 +138,7 @@ def hip_run(out, tag, steps, every, seed, train_precision, graph, rng):
         else:
             b = run.dataset.gather(torch.randint(0, len(run.dataset), (BATCH,), generator=pick).to(dev))
         run.iteration += 1
-        losses.append(run.train_step(b))
+        losses.append(torch.as_tensor(run.train_step(b)).detach().reshape(()).clone())   # (a replay returns its static tensor)
         if step % every == 0 or step == steps:
             psnrs[step] = run.evaluate()
             print(f"[{tag}] step {step}: loss {float(losses[-1]):.6f}, held-out PSNR {psnrs[step]:.4f} dB, "
@@ -148,7 +148,7 @@ def hip_run(out, tag, steps, every, seed, train_precision, graph, rng):
     result = {"tag": tag, "kind": "HIP Trainer (nerf_amd.trainer.Trainer)", "train_precision": train_precision,
               "graph_replay": bool(graph), "replayed": run._graph is not None, "seed": seed,
               "draws": "captured stream" if rng == "captured" else "in-kernel Philox", "steps": steps,
-              "seconds": seconds, "loss": [float(x) for x in torch.stack([torch.as_tensor(l).reshape(()) for l in losses]).cpu()],
+              "seconds": seconds, "loss": [float(x) for x in torch.stack(losses).cpu()],
               "psnr": psnrs}
     with open(os.path.join(out, f"traj_{tag}.json"), "w") as f:
         json.dump(result, f)
@@ -200,10 +200,26 @@ def merge(out, path):
                     row[t] = r["psnr"][step]
                     row["d_" + t] = abs(r["psnr"][step] - base["psnr"][step])
             table[step] = row
+        oracles = sorted(t for t, r in runs.items() if r["draws"] == "captured stream" and r["kind"].startswith("oracle"))
+        steps_sorted = sorted(base["psnr"], key=int)
+        late = steps_sorted[len(steps_sorted) // 2:]                   # the second half of the run: "converged"
+        floor = {}
+        for step in steps_sorted:
+            d = [abs(runs[a]["psnr"][step] - runs[b]["psnr"][step]) for i, a in enumerate(oracles) for b in oracles[i + 1:]]
+            floor[step] = {"pairs": len(d), "median": float(np.median(d)) if d else None, "max": max(d) if d else None}
+        late_mean = {t: float(np.mean([r["psnr"][s] for s in late])) for t, r in runs.items()
+                     if r["draws"] == "captured stream"}
         record["captured_draws"] = {
+            "oracle_pair_floor": {"what": "|PSNR_a - PSNR_b| over every pair of oracle runs (same algorithm, same draws, "
+                                          "thread counts " + ", ".join(str(runs[t]["threads"]) for t in oracles) + ")",
+                                  "per_checkpoint": floor},
+            "late_mean_psnr": {"what": f"mean held-out PSNR over steps {late[0]} .. {late[-1]}", "values": late_mean,
+                               "oracle_spread": max(late_mean[t] for t in oracles) - min(late_mean[t] for t in oracles),
+                               "hip_minus_oracle_mean": {t: late_mean[t] - float(np.mean([late_mean[o] for o in oracles]))
+                                                         for t in late_mean if t not in oracles}},
             "checkpoints": table,
-            "noise_floor": "d_cpu_1t = |PSNR(oracle, 1 thread) - PSNR(oracle, 14 threads)|: the same algorithm, the same "
-                           "draws, two summation orders",
+            "noise_floor": "d_cpu_1t / d_cpu_2t / d_cpu_4t = |PSNR(oracle, n threads) - PSNR(oracle, 8 threads)|: the same "
+                           "algorithm, the same draws, other summation orders",
             "max_abs_dpsnr": {t: max(row.get("d_" + t, 0.0) for row in table.values())
                               for t in runs if t != "cpu_mt" and runs[t]["draws"] == "captured stream"},
             "max_rel_loss_deviation": {
@@ -238,7 +254,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r6_psnr"))
     ap.add_argument("--part", choices=("captured", "rng"), default="captured")
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--every", type=int, default=250)
+    ap.add_argument("--every", type=int, default=100)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--tag", default="cpu_mt")
     ap.add_argument("--threads", type=int, default=16)
@@ -253,8 +269,9 @@ def main():
         return merge(args.out, args.json)
     # run: the oracle trajectories first, as children, before this process touches the GPU
     if args.part == "captured":
-        kids = [spawn_oracle(args.out, "cpu_1t", 1, args.steps, args.every, args.seed, False),
-                spawn_oracle(args.out, "cpu_mt", 14, args.steps, args.every, args.seed, False)]
+        # four summation orders of the SAME algorithm on the SAME draws (1 + 2 + 4 + 8 = 15 of the box's 16 CPUs)
+        kids = [spawn_oracle(args.out, f"cpu_{t}t" if t < 8 else "cpu_mt", t, args.steps, args.every, args.seed, False)
+                for t in (1, 2, 4, 8)]
         for tag, prec, graph in (("hip_fp32", "fp32", False), ("hip_f16x3", "f16x3", False),
                                  ("hip_f16x3_graph", "f16x3", True), ("hip_fp32_graph", "fp32", True)):
             hip_run(args.out, tag, args.steps, args.every, args.seed, prec, graph, "captured")

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(handle):
     ge = handle.nerf_hip_grad_elements
     assert ge(256, 96, 54) == 304438                          # the reference's defaults: hidden 256, 3 x 32 inputs, 1 + 3 + 50 outputs
     assert ge(256, 96, 4) == 304438 - 50 * 257 and ge(256, 96, 64) == 304438 + 10 * 257
-    assert ge(256, 96, 3) == 0 and ge(256, 96, 65) == 0
+    assert ge(256, 96, 1) == 0 and ge(256, 96, 65) == 0 and ge(256, 96, 2) == 304438 - 52 * 257      # (density + 1 color)
     # narrower networks (run zero-padded inside the kernels): sum of the 22 tensors' PyTorch sizes
     for hid, enc, n_out in ((128, 96, 54), (256, 48, 54), (64, 48, 11), (17, 6, 4)):
         want = hid * enc + hid + 4 * (hid * hid + hid) + 10 * hid + n_out * hid + n_out
@@ -96,12 +96,16 @@ def test_argument_errors_do_not_touch_the_gpu(handle):
     assert b"num_outputs" in handle.nerf_hip_last_error()
     args.num_outputs = 65
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -2
-    args.num_outputs = 54
+    args.num_outputs, args.color_outputs = 54, 13              # more color channels than output tile 0 holds
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -2
+    args.num_outputs, args.color_outputs = 5, 5                # 1 + colors > rows
+    assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -2
+    args.num_outputs, args.color_outputs = 54, 0               # 0 = the reference's 3
     args.precision = 7
     assert handle.nerf_hip_render_forward(ctypes.byref(args), None) == -1
     assert b"precision" in handle.nerf_hip_last_error()
     assert handle.nerf_hip_build_flags() == b""          # the product build carries no experiment macro
-    assert handle.nerf_hip_pack_weights(None, 256, 96, 54, None, None) == -1
+    assert handle.nerf_hip_pack_weights(None, 256, 96, 54, 3, None, None) == -1
     assert handle.nerf_hip_render_backward(None, None) == -1
     bargs = _lib.BackwardArgs()
     assert handle.nerf_hip_render_backward(ctypes.byref(bargs), None) == -1

@@ -60,6 +60,26 @@ def test_defaults_are_the_reference_arithmetic_and_the_one_frame_partition(monke
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
 
 
+def test_secondary_timings_carry_a_spread():
+    """Every secondary figure is REPEATS loops of >= 50 steps (anything under 10 ms) or >= 5 steps (frames) with
+    min / median / max in the entry (round-5 verdict: boxes differ by 4-6 %, targets sit 1-5 % away)."""
+    import bench
+    assert bench.REPEATS >= 5 and bench.SHORT_STEPS >= 50 and bench.FRAME_STEPS >= 5
+    sp = bench.spread([3.0, 1.0, 2.0, 5.0, 4.0])
+    assert (sp["min"], sp["median"], sp["max"], sp["loops"]) == (1.0, 3.0, 5.0, 5)
+    assert bench.spread([1.0, 2.0, 3.0, 4.0])["median"] == 2.5
+    src = open(bench.__file__).read()
+    for fn in ("train_step_timing", "legacy_train_step_timing", "small_batch_step_timing", "legacy_workload_timing",
+               "baseline_configs"):
+        body = src[src.index("def " + fn):]
+        body = body[:body.index("\ndef ", 10)]
+        assert "timed_loops(" in body and "spread(" in body, fn
+    for fn in ("train_step_timing", "legacy_train_step_timing"):      # per-kernel split of a training step
+        body = src[src.index("def " + fn):]
+        assert "kernel_split(" in body[:body.index("\ndef ", 10)], fn
+    assert bench.train_tiles_of(256) == 16 and bench.train_tiles_of(128) == 8
+
+
 def _bench(*argv, env=None, timeout=600):
     import subprocess
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -86,6 +106,10 @@ def test_plain_gpus_8_starts_its_own_eight_ranks_dry_run():
     assert dp["rays_per_rank"] == 512 and dp["global_batch"] == 4096
     assert dp["batch_blocks"] == [[512 * r, 512 * (r + 1)] for r in range(8)]
     assert dp["gradient_bytes"] == 304438 * 4 and dp["flat_all_reduce_matches_weighted_sum"] is True
+    assert dp["scaling"] == "strong"
+    weak = line["train_step_dp_weak"]              # the weak form of the same entry: 4096 rays PER RANK
+    assert weak["scaling"] == "weak" and weak["rays_per_rank"] == 4096 and weak["global_batch"] == 8 * 4096
+    assert weak["batch_blocks"] == [[4096 * r, 4096 * (r + 1)] for r in range(8)]
 
 
 def test_launcher_and_gpus_disagreeing_is_a_message_not_an_assert():

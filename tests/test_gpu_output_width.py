@@ -16,14 +16,24 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-# (segmentation classes, hidden_size, encoding_size)
-SHAPES = [(0, 256, 32), (7, 256, 32), (60, 256, 32), (50, 128, 32), (50, 256, 16), (7, 64, 16), (3, 40, 10)]
+# (segmentation classes, hidden_size, encoding_size[, color_outputs = 3])
+# color_outputs (nerf/model.py:471, :541-542, :591-592, :660) 1, 4, 7 and 12: the channels sit three per lane group in
+# output tile 0 (nerf_layout.h: color_slot), so 4 and 7 cross into lane groups 1 and 2 and the classes fill the slots
+# between them; 12 with 51 classes is the full 64-row tile; (0 classes, 4 colors) leaves a padding slot INSIDE the tile
+SHAPES = [(0, 256, 32), (7, 256, 32), (60, 256, 32), (50, 128, 32), (50, 256, 16), (7, 64, 16), (3, 40, 10),
+          (50, 256, 32, 1), (50, 256, 32, 4), (0, 256, 32, 4), (9, 128, 32, 7), (51, 256, 32, 12), (0, 64, 16, 1)]
+
+
+def colors_of(shape):
+    return shape[3] if len(shape) > 3 else 3
 
 
 def setup(shape, seed, scale=2.0):
     from nerf_amd import NeRF
-    classes, hidden, enc = shape
-    cfg = dict(O.default_config(), segmentation_outputs=classes, hidden_size=hidden, encoding_size=enc)
+    classes, hidden, enc = shape[:3]
+    colors = colors_of(shape)
+    cfg = dict(O.default_config(), segmentation_outputs=classes, hidden_size=hidden, encoding_size=enc,
+               color_outputs=colors)
     params = O.init_params(seed=seed, cfg=cfg)
     for slot in O.LINEAR_IDS:
         params[f"prediction_heads.{slot}.weight"] = params[f"prediction_heads.{slot}.weight"] * scale
@@ -31,7 +41,7 @@ def setup(shape, seed, scale=2.0):
     for k in list(params):                              # non-trivial LayerNorm affine and biases
         if k.startswith("prediction") and params[k].dim() == 1:
             params[k] = params[k] + 0.2 * torch.randn_like(params[k])
-    model = NeRF(segmentation_outputs=classes, hidden_size=hidden, encoding_size=enc)
+    model = NeRF(segmentation_outputs=classes, hidden_size=hidden, encoding_size=enc, color_outputs=colors)
     assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v.shape) for k, v in params.items()}
     model.load_state_dict(params)
     return cfg, params, model.to(torch.device("cuda:0"))
@@ -45,10 +55,10 @@ def rel_err(a, b):
 @pytest.mark.parametrize("shape", SHAPES)
 def test_forward_vs_oracle(shape, precision):
     dev = torch.device("cuda:0")
-    classes = shape[0]
+    classes, colors = shape[0], colors_of(shape)
     cfg, params, model = setup(shape, seed=classes)
     model.precision = precision
-    assert model.num_outputs == 4 + classes and model.enc_inputs == 3 * shape[2]
+    assert model.num_outputs == 1 + colors + classes and model.enc_inputs == 3 * shape[2]
     n, S = 77, 40
     g = torch.Generator().manual_seed(3)
     cam_o = torch.tensor([[0.0, -3.0, 2.6]])
@@ -61,8 +71,9 @@ def test_forward_vs_oracle(shape, precision):
         mean, density, color, seg_logits = model.forward(rays_o.to(dev), rays_d.to(dev), st["t"].to(dev))
         img, img_seg = model.render_image(cam_o.to(dev), cam_r.to(dev), 11, 7, 12.3, S)
         det_rgb, det_seg = O.render_rays(params, cfg, rays_o, rays_d, S)
-    assert rgb.shape == (n, 1, 3) and seg.shape == (n, 1, classes) and seg_logits.shape == (n, S - 1, classes)
-    assert img.shape == (1, 11, 7, 3) and img_seg.shape == (1, 11, 7, classes)
+    assert rgb.shape == (n, 1, colors) and seg.shape == (n, 1, classes) and seg_logits.shape == (n, S - 1, classes)
+    assert color.shape == (n, S - 1, colors) and density.shape == (n, S - 1, 1)
+    assert img.shape == (1, 11, 7, colors) and img_seg.shape == (1, 11, 7, classes)
     assert (density.cpu() - st["density"]).abs().max() <= 2e-5 * max(1.0, float(st["density"].abs().max()))
     assert (color.cpu() - st["color"]).abs().max() <= 2e-5 * max(1.0, float(st["color"].abs().max()))
     ok = st["density"][:, -1, 0].abs() > 1e-5                       # the 1e10-wide last interval
@@ -94,7 +105,7 @@ def test_forward_vs_oracle(shape, precision):
         assert float(seg[:, 0].exp().sum(-1).max()) <= 1.0 + 1e-4
     with torch.no_grad():
         det = O.render_rays(params, cfg, rays_o, rays_d, S, return_stages=True)[2]["density"][:, -1, 0].abs() > 1e-5
-    assert (img.reshape(-1, 3).cpu() - det_rgb)[det].abs().max() <= 1e-5
+    assert (img.reshape(-1, colors).cpu() - det_rgb)[det].abs().max() <= 1e-5
     if classes:
         assert (img_seg.reshape(-1, classes).cpu() - det_seg)[det].abs().max() <= 1e-4
 
@@ -103,7 +114,8 @@ def test_forward_vs_oracle(shape, precision):
 @pytest.mark.parametrize("shape", SHAPES)
 def test_gradients_vs_oracle_autograd(shape, train_precision):
     dev = torch.device("cuda:0")
-    classes, hidden, enc = shape
+    classes, hidden, enc = shape[:3]
+    colors = colors_of(shape)
     cfg, params, model = setup(shape, seed=10 + classes)
     model.train_precision = train_precision
     n, S = 70, 33
@@ -111,7 +123,7 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
     o, d = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
     u = torch.rand(n, S, generator=g)
     noise = torch.randn(n, S - 1, 1, generator=g)
-    w_rgb = torch.randn(n, 3, generator=g)
+    w_rgb = torch.randn(n, colors, generator=g)
     w_seg = torch.randn(n, classes, generator=g) * 0.05
 
     def loss_of(p, cast):
@@ -134,7 +146,7 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
     assert abs(float(loss.detach()) - loss_r) <= 1e-4 * max(1.0, abs(loss_r))
     assert model.last_flat_grad.numel() == sum(p.numel() for p in model.parameters())
     if (hidden, enc) == (256, 32):
-        assert model.last_flat_grad.numel() == 304438 + (classes - 50) * 257
+        assert model.last_flat_grad.numel() == 304438 + (classes + colors - 53) * 257
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == ref[k].shape, k
         e = rel_err(p.grad.cpu(), ref[k])
@@ -156,7 +168,7 @@ def test_layer_norm_with_a_large_common_bias(shape, strength, precision):
     carries 4e-6 of absolute rounding, 1e-5 of its std), so the forward is held to the fp64 oracle within 4 x the
     fp32 oracle's own distance from it."""
     dev = torch.device("cuda:0")
-    classes, hidden, enc = shape
+    classes, hidden, enc = shape[:3]
     cfg, params, model = setup(shape, seed=40 + classes)
     params["prediction_heads.0.bias"] = params["prediction_heads.0.bias"] + 6.0 * strength
     params["prediction_heads.6.bias"] = params["prediction_heads.6.bias"] - 9.0 * strength
@@ -251,6 +263,6 @@ def test_shapes_the_kernels_do_not_take_are_refused():
     dev = torch.device("cuda:0")
     o = torch.randn(4, 3, device=dev)
     for kwargs in (dict(segmentation_outputs=61), dict(hidden_size=257), dict(encoding_size=34), dict(encoding_size=15),
-                   dict(color_outputs=4)):
+                   dict(color_outputs=13), dict(color_outputs=0), dict(color_outputs=12, segmentation_outputs=52)):
         with pytest.raises(NotImplementedError):
             NeRF(**kwargs).to(dev).render_rays(o, o, 8)

@@ -220,6 +220,9 @@ def test_the_drivers_multi_gpu_bench_command_runs_as_a_rehearsal(tmp_path):
     assert dp["gradient_bytes"] == 304438 * 4 and dp["replicas_identical"] is True and dp["parameters_finite"] is True
     assert dp["eager"]["ms_per_step"] > 0 and dp["eager"]["allreduce_ms"] > 0
     assert dp["graph"]["ms_per_step"] > 0 and dp["graph"]["collective_and_optimiser_in_graph"] is False   # gloo: outside
+    weak = line["train_step_dp_weak"]
+    assert weak["scaling"] == "weak" and weak["rays_per_rank"] == 4096 and weak["global_batch"] == 8192
+    assert weak["replicas_identical"] is True and weak["parameters_finite"] is True
 
 
 def test_plain_bench_gpus_n_starts_its_own_ranks(tmp_path):
@@ -248,7 +251,11 @@ def test_plain_bench_gpus_n_starts_its_own_ranks(tmp_path):
     assert line["weak_scaling"]["frames"] == 4
     dp = line["train_step_dp"]
     assert dp["rays_per_rank"] == 1024 and dp["global_batch"] == 4096 and dp["gradient_bytes"] == 304438 * 4
-    assert dp["replicas_identical"] is True and dp["parameters_finite"] is True
+    assert dp["replicas_identical"] is True and dp["parameters_finite"] is True and dp["scaling"] == "strong"
+    weak = line["train_step_dp_weak"]              # 4096 rays PER RANK: what an 8-GPU record needs to isolate RCCL's cost
+    assert weak["scaling"] == "weak" and weak["rays_per_rank"] == 4096 and weak["global_batch"] == 4 * 4096
+    assert weak["rendezvous_backend"] == "gloo" and weak["replicas_identical"] is True and weak["parameters_finite"] is True
+    assert weak["eager"]["ms_per_step"] > 0 and weak["graph"]["ms_per_step"] > 0
 
 
 def _rccl_single_rank_worker(rank, world, port, out_dir):
