@@ -35,8 +35,26 @@ struct LazyNorm {
     float rstd, shift;          // x_hat = fma(x, rstd, shift), shift = -mean * rstd
     const f32x4* gam;           // this lane group's gamma / beta in LDS: tile T at [T]
     const f32x4* bet;
-    float* save_row;            // training: this lane's x_hat of register tile 0 (tile T at + kTileT T), else unused
+    float* save_row;            // training: this lane's x_hat of register tile 0 (tile T at + kTileT T), else unused.
+                                // kOrderReluNorm (the legacy network's kernels): the wave's UNIFORM tile base, the
+                                // lane's offset inside the tile is taken at every use (row_lane_offset below)
 };
+
+// A lane's constant 32-bit offset behind an optimisation barrier, taken at every use: with a wave-uniform 64-bit base
+// (scalar registers) + this offset a saved row needs no per-lane 64-bit pointer — otherwise loop-invariant code
+// motion folds base + offset + tensor offset into one such pointer per saved tensor and parks them all across the
+// layers (the legacy training forward: 30 spilled address registers; nerf_backward.hip uses the same form).
+__device__ __forceinline__ uint32_t lane_offset(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// ... of this lane's f32x4 inside a tile-major 16-sample tile (nerf_device.h: tile_lane_word(j, g)) and inside a
+// [16] per-sample statistic, from the thread id alone (three integer operations per use, nothing kept)
+__device__ __forceinline__ uint32_t row_lane_offset() {
+    const uint32_t l = lane_offset(threadIdx.x);
+    return ((l >> 4) & 3u) * 64u + (l & 15u) * 4u;
+}
+__device__ __forceinline__ uint32_t stat_lane_offset() { return lane_offset(threadIdx.x) & 15u; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -90,7 +108,7 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
             if (kTrain) xh[r] = (x[r] > 0.f && xh[r] <= n.shift) ? above : xh[r];
             x[r] = __builtin_fmaf(xh[r], ga[r], be[r]);
         }
-        if (kTrain) *(f32x4*)(n.save_row + T * kTileT) = xh;
+        if (kTrain) *(f32x4*)(n.save_row + row_lane_offset() + T * kTileT) = xh;
         return;
     }
     if (kPacked) {
@@ -132,6 +150,8 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
                                                       float* save_rstd, float eps = 1e-5f,
                                                       float save_scale = 1.0f, float* save_shift = nullptr,
                                                       const NormDivisor nd = kFullWidth) {
+    // (kOrderReluNorm: save_row / save_rstd / save_shift are wave-uniform bases of the sample tile, the lane's offsets
+    //  are added where they are used; else per-lane pointers)
     const float mean = group_sum(m.sum()) * nd.inv_n;
     const float ex2 = group_sum(m.sum_sq()) * nd.inv_n;
     float var = ex2 - mean * mean;
@@ -162,11 +182,14 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
     const float ve = var + eps;
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-    if (kTrain && g == 0) *save_rstd = rstd * save_scale;
+    if (kTrain && g == 0) {
+        if (kOrder == kOrderReluNorm) save_rstd[stat_lane_offset()] = rstd * save_scale;
+        else *save_rstd = rstd * save_scale;
+    }
     LazyNorm n;
     n.rstd = rstd;
     n.shift = -mean * rstd;
-    if (kTrain && kOrder == kOrderReluNorm && g == 0) *save_shift = n.shift;      // (x_hat, so scale-free)
+    if (kTrain && kOrder == kOrderReluNorm && g == 0) save_shift[stat_lane_offset()] = n.shift;   // (x_hat, so scale-free)
     n.gam = gam;
     n.bet = bet;
     n.save_row = save_row;
@@ -201,13 +224,15 @@ typedef MomentsPk HMoments;
 // built (normalise tile by tile, then split) during stage (0, m).
 // NT = 8 (a narrow network, nerf_layout.h: kNarrowH8Offset): ONE half — a stage = the eight out tiles of k block m —
 // so every tile completes in the last stage and the moments ride there, a unit behind.
+// layer_fused_hb: the same with the B operands (the f16 pairs of the normalised input, k block by k block) in the
+// CALLER's registers, for a caller that multiplies the same input once more behind the layer (the legacy network's
+// density head on x'_7): it then reads the pairs instead of keeping the 16 fp32 input tiles alive across this layer.
 template <int KB, bool kNormIn, bool kTrain, int kOrder = kOrderNormRelu, int NT = 16, class Pipe>
-__device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
-                                              const LazyNorm& norm, HMoments& mom) {
+__device__ __forceinline__ void layer_fused_hb(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
+                                               const LazyNorm& norm, HMoments& mom, h8 (&bhi)[KB], h8 (&blo)[KB]) {
     static_assert(NT == 16 || NT == 8, "out tiles in halves of eight");
     constexpr int kHalves = NT / 8;
     constexpr int kStages = kHalves * KB, kUnits = 8 * kStages;
-    h8 bhi[KB], blo[KB];
     if (kNormIn) {
         normalize_tile<kTrain, kPackNorm, kOrder>(in[0], norm, 0);
         normalize_tile<kTrain, kPackNorm, kOrder>(in[1], norm, 1);
@@ -293,6 +318,12 @@ __device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4
     }
     mom.template add<kOrder>(out[NT - 1]);
     __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+}
+template <int KB, bool kNormIn, bool kTrain, int kOrder = kOrderNormRelu, int NT = 16, class Pipe>
+__device__ __forceinline__ void layer_fused_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (&out)[16],
+                                              const LazyNorm& norm, HMoments& mom) {
+    h8 bhi[KB], blo[KB];
+    layer_fused_hb<KB, kNormIn, kTrain, kOrder, NT>(pipe, in, out, norm, mom, bhi, blo);
 }
 
 }  // namespace nerf_fused

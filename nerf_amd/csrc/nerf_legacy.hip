@@ -395,6 +395,31 @@ __device__ __forceinline__ f32x4 head_layer_h(LegacyHPipe& pipe, f32x4 acc, f32x
     return acc;
 }
 
+// The density head on k blocks that are ALREADY f16 pairs (the B operands L8's fused loop built from x'_7,
+// nerf_fused.h: layer_fused_hb): the same eight stages, splits and MFMA order as head_layer_h<false> on the fp32
+// tiles — bit-identical — without holding those 16 tiles across L8 (64 registers in every layer of the shared X -> Y
+// code instance: what the 256-register training kernel spilled inside its loops).
+__device__ __forceinline__ f32x4 head_layer_hb(LegacyHPipe& pipe, f32x4 acc, const h8 (&bhi)[8], const h8 (&blo)[8]) {
+    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    const h8* st = (const h8*)pipe.open_stage();
+    h8 ah[2], al[2];
+    ah[0] = st[0];
+    al[0] = st[64];
+    pipe.prefetch_next();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m + 1 < 8) {
+            ah[(m + 1) & 1] = st[(2 * m + 2) * 64];
+            al[(m + 1) & 1] = st[(2 * m + 3) * 64];
+        }
+        acc = mfma_h(ah[m & 1], bhi[m], acc);
+        acc = mfma_h(ah[m & 1], blo[m], acc);
+        acc = mfma_h(al[m & 1], bhi[m], acc);
+    }
+    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+    return acc;
+}
+
 // kTrain: the training forward in this arithmetic (LegacyNeRF8x256.train_precision = "f16x3"): one (padded ray,
 // chunk) item per wave, compositing in its own kernel, the same saves as the fp32 training forward
 // (nerf_legacy_fwd_kernel<true>) into the same workspace — a_hat is scale-free, 1/std is un-scaled by 2^12 —
@@ -464,9 +489,11 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 r.d[1] = ray_stash[4], r.d[2] = ray_stash[5];
                 return r;
             };
-            // training: lane-relative bases of this sample's saved rows (+ the tensor's offset)
-            float* const xrow = kTrain ? ws + tile_lane_base(sp, g) : nullptr;      // (tile-major rows)
-            float* const stat = kTrain ? ws + sp : nullptr;
+            // training: the wave's UNIFORM tile bases of the saved rows (+ the tensor's offset), and this lane's 32-bit
+            // offsets inside a tile are taken where they are used (nerf_fused.h: row_lane_offset — no per-lane 64-bit
+            // pointer lives across the layers)
+            float* const xrow = kTrain ? ws + tile * kTileFloats : nullptr;         // (tile-major rows)
+            float* const stat = kTrain ? ws + tile * 16 : nullptr;                  // (+ j)
             f32x4 X[16], Y[16];                   // a layer's input tiles (B operands) / its accumulators, in turn
             {
                 const Ray ray = the_ray();
@@ -483,10 +510,13 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     *stash_dist = dist;
                 }
                 float pos_act[64];
-                encode_position(ray, t0, la, g, pos_act);
+                // (the encoders' per-lane constants — frequencies of lane group g — behind the optimisation barrier of
+                //  nerf_fused.h: lane_offset: hoisted out of the ray loop they are ten registers parked across every layer)
+                const int ge = kTrain ? (int)nerf_fused::lane_offset((uint32_t)g) : g;
+                encode_position(ray, t0, la, ge, pos_act);
                 if (kTrain) {                     // both encodings as rows (un-scaled, as the fp32 forward saves them)
                     float dir_act[64];
-                    encode_direction(ray, dlen, la, g, dir_act);
+                    encode_direction(ray, dlen, la, ge, dir_act);
                     float* prow = ws + ka.save.pos + sp * kEncPad + 4 * g;
                     float* drow = ws + ka.save.dir + sp * kEncPad + 4 * g;
 #pragma unroll
@@ -522,16 +552,21 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 if (p == 4) break;
                 const float* sb = sa + kLegacySmallPerLayer;                          // L2, L4, L6, L8
                 load_bias(sb, g, Y);
-                nerf_fused::layer_fused_h<8, true, kTrain, kOrderReluNorm>(pipe, X, Y, norm, mom);
+                // training: the layer's B operands (x' of the layer below as f16 pairs) stay with the caller for the
+                // density head; the inference kernel, with fewer live addresses, is better off re-splitting the tiles
+                h8 xb_hi[8], xb_lo[8];
+                if constexpr (kTrain) nerf_fused::layer_fused_hb<8, true, kTrain, kOrderReluNorm>(pipe, X, Y, norm, mom, xb_hi, xb_lo);
+                else nerf_fused::layer_fused_h<8, true, kTrain, kOrderReluNorm>(pipe, X, Y, norm, mom);
                 if (p & 1) {
                     // L4: + [encoded position], L8: + [encoded direction]: two more k blocks, encoded here
                     h8 eh[2], el[2];
                     {
                         const Ray ray = the_ray();
                         float enc[64];
-                        if (p == 1) encode_position(ray, *stash_t0, la, g, enc, kX);
+                        const int ge = kTrain ? (int)nerf_fused::lane_offset((uint32_t)g) : g;
+                        if (p == 1) encode_position(ray, *stash_t0, la, ge, enc, kX);
                         else encode_direction(ray, __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]),
-                                              la, g, enc, kX);
+                                              la, ge, enc, kX);
                         split_block(enc, 0, eh[0], el[0]);
                         split_block(enc, 1, eh[1], el[1]);
                     }
@@ -539,9 +574,10 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     mom.reset();
 #pragma unroll
                     for (int T = 0; T < 16; ++T) mom.template add<kOrderReluNorm>(Y[T]);
-                    if (p == 3) {                 // density head on x'_7 (normalised in place by L8's fused loop)
+                    if (p == 3) {                 // density head on x'_7: the pairs L8's fused loop made of it
                         const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-                        dens = head_layer_h<false, kTrain>(pipe, hb[g], X, norm).x * kUn;
+                        if constexpr (kTrain) dens = head_layer_hb(pipe, hb[g], xb_hi, xb_lo).x * kUn;
+                        else dens = head_layer_h<false, kTrain>(pipe, hb[g], X, norm).x * kUn;
                     }
                 }
                 norm = nerf_fused::finish_moments_at<kTrain, HMoments, kOrderReluNorm>(

@@ -175,13 +175,22 @@ def ipe_features(means, covs, min_deg, max_deg):
 # a9: the MLP
 # --------------------------------------------------------------------------
 
-def mlp(params, h):
-    """prediction_heads: Linear -> (LayerNorm -> ReLU -> Linear) x 5  (model.py:525-542)."""
+def mlp(params, h, gates=None, record=None):
+    """prediction_heads: Linear -> (LayerNorm -> ReLU -> Linear) x 5  (model.py:525-542).
+
+    Test aids (not in the reference): ``record`` — a list that receives the five ReLU gates (LayerNorm output > 0)
+    this evaluation ran with; ``gates`` — five boolean tensors to run with INSTEAD (x * gate in place of relu(x)).  A
+    gradient is discontinuous in every gate, and a gate within rounding of zero falls on either side depending on the
+    summation order of the LayerNorm that feeds it: forcing the gates another implementation reports makes both sides
+    differentiate the same piecewise-linear function, so that their gradients can be compared at arithmetic accuracy
+    and the flipped gates be counted separately."""
     x = F.linear(h, params["prediction_heads.0.weight"], params["prediction_heads.0.bias"])
-    for norm_slot, lin_slot in zip(NORM_IDS, LINEAR_IDS[1:]):
+    for i, (norm_slot, lin_slot) in enumerate(zip(NORM_IDS, LINEAR_IDS[1:])):
         x = F.layer_norm(x, (x.shape[-1],), params[f"prediction_heads.{norm_slot}.weight"],
                          params[f"prediction_heads.{norm_slot}.bias"], 1e-5)
-        x = F.relu(x)
+        if record is not None:
+            record.append((x > 0).detach())
+        x = F.relu(x) if gates is None else x * gates[i].to(x.dtype)
         x = F.linear(x, params[f"prediction_heads.{lin_slot}.weight"],
                      params[f"prediction_heads.{lin_slot}.bias"])
     return x
@@ -208,12 +217,12 @@ def mlp_stages(params, h):
     return x, x_hats, rstds
 
 
-def field(params, cfg, rays_o, rays_d, t):
-    """NeRF.forward (model.py:553-594): returns means, covs, h, density, color, seg."""
+def field(params, cfg, rays_o, rays_d, t, gates=None, record=None):
+    """NeRF.forward (model.py:553-594): returns means, covs, h, density, color, seg.  (gates / record: ``mlp``.)"""
     base_radius = 1 / (np.sqrt(3) * cfg["focal_length"])                       # :546
     means, covs = frustum_gaussians(rays_o, rays_d, t, base_radius)
     h = ipe_features(means, covs, -4, cfg["encoding_size"] // 2 - 4)           # :550-551
-    out = mlp(params, h)
+    out = mlp(params, h, gates=gates, record=record)
     density, color, seg = out.split(
         [1, cfg["color_outputs"], cfg["segmentation_outputs"]], dim=-1)         # :591-592
     return means, covs, h, density, color, seg
@@ -233,14 +242,14 @@ def composite_weights(points, density):
 
 
 def render_rays(params, cfg, rays_o, rays_d, num_samples, u=None, noise=None,
-                density_noise_std=0.0, return_stages=False):
+                density_noise_std=0.0, return_stages=False, gates=None, record=None):
     """NeRF.render_rays (model.py:596-668) without the stage axis.
 
     ``u`` [N,S] / ``noise`` [N,S-1,1] stand for the torch.rand (:432) and
     torch.randn (:652) draws.  Returns rgb [N,3], seg [N,50] (log-probs)."""
     n_rays = rays_o.shape[0]
     t = sample_t(params, n_rays, num_samples, u)
-    means, covs, h, density, color, seg = field(params, cfg, rays_o, rays_d, t)
+    means, covs, h, density, color, seg = field(params, cfg, rays_o, rays_d, t, gates=gates, record=record)
     if noise is not None:
         density = density + noise * density_noise_std                           # :652-654
     weights = composite_weights(means, density)                                 # :658
@@ -298,10 +307,10 @@ def look_at_pose(camera_o):
     return rotation_from_eye_up(eye, up)
 
 
-def training_loss(params, cfg, rays_o, rays_d, num_samples, target, u, noise, noise_std):
-    """MSE of train_conditional_nerf.py:132 on the generation-C output shape."""
+def training_loss(params, cfg, rays_o, rays_d, num_samples, target, u, noise, noise_std, gates=None, record=None):
+    """MSE of train_conditional_nerf.py:132 on the generation-C output shape.  (gates / record: ``mlp``.)"""
     rgb, _ = render_rays(params, cfg, rays_o, rays_d, num_samples, u=u, noise=noise,
-                         density_noise_std=noise_std)
+                         density_noise_std=noise_std, gates=gates, record=record)
     return ((rgb.unsqueeze(1) - target.unsqueeze(1)) ** 2).mean()
 
 

@@ -1,0 +1,59 @@
+"""Gate-aware gradient comparison for the main network (tests/test_legacy_backward.py does the same for the legacy one).
+
+A parameter gradient is discontinuous in every ReLU gate, and a gate whose pre-activation sits within rounding of zero
+falls on either side depending on the summation order of the LayerNorm that feeds it — one such gate moves a gradient
+tensor by 1e-4 of its largest element (round 5: the first G11 fixture).  So the comparison is split in two:
+
+* the ARITHMETIC: the oracle differentiates with the gates the KERNEL ran with (read from the workspace its training
+  forward saved: fma(x_hat, gamma, beta) > 0, tests/workspace_mirror.py: saved_gates), i.e. both sides differentiate
+  the same piecewise-linear function — every gradient tensor must agree to ``grad_bound`` of its largest element;
+* the GATES: the kernel's gates against the oracle's own — they may differ only in a bounded share of elements
+  (``flip_bound``), the ones within rounding of zero.
+
+No fixture has to be picked for having no borderline gate."""
+import torch
+
+import workspace_mirror as W
+
+GRAD_BOUND = 1e-5            # measured <= 2e-6 (fp32) / 3e-6 (f16x3)
+FLIP_BOUND = 1e-5            # share of gates that may differ from the oracle's own
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def kernel_gates(model, params, n_rays, num_samples):
+    """Gates of the training forward ``model`` just ran (``model.keep_workspace`` must have been set before it)."""
+    return W.saved_gates(model.last_workspace, params, n_rays, num_samples)
+
+
+def oracle_gradients(params, loss_fn, gates=None, record=None, dtype=torch.float32):
+    p = {k: v.to(dtype).clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
+    loss = loss_fn(p, gates, record)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.float() for k, v in p.items() if v.grad is not None}
+
+
+def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, flip_bound=FLIP_BOUND, tag=""):
+    """``loss_fn(p, gates, record)``: the oracle's loss on parameter dict ``p`` (its dtype), passing ``gates`` /
+    ``record`` through to oracle.nerf_oracle.mlp.  ``model`` holds the kernel's gradients (p.grad) of the same loss.
+    Returns (flips, total, worst error, the oracle's gradients on its OWN gates)."""
+    gates = kernel_gates(model, params, n_rays, num_samples)
+    own = []
+    _, plain = oracle_gradients(params, loss_fn, record=own)
+    _, ref = oracle_gradients(params, loss_fn, gates=gates)
+    assert len(own) == len(gates) == 5 and all(a.shape == b.shape for a, b in zip(own, gates))
+    flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
+    total = sum(a.numel() for a in gates)
+    assert flips <= max(flip_bound * total, 2), (flips, total)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == ref[k].shape, k
+        e = rel_err(p.grad.cpu(), ref[k])
+        worst = max(worst, e)
+        assert e <= grad_bound, (k, e)
+    print(f"[{tag}] worst relative gradient error on the kernel's gates {worst:.2e}; {flips} of {total} gates differ from "
+          f"the oracle's own (against the oracle on ITS gates: "
+          f"{max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
+    return flips, total, worst, plain

@@ -226,37 +226,38 @@ def main():
     # ---- G11: NARROW networks (constructor keywords of nerf/model.py:471-475): render + one training gradient ----
     # hidden_size 128 / encoding 32 / 50 classes, hidden 64 / encoding 16 / 7 classes, hidden 40 / encoding 10 / 3 classes
     # — what the kernels instantiated at 8 and 4 register tiles per sample are held to (weights x 2: sharper fields)
+    # ---- G12: other color_outputs (constructor keyword of nerf/model.py:471; :541-542, :591-592, :660) -----------------
+    # 1 channel with the default 50 classes; 4 channels (crossing into the kernels' second lane group of colors) on a
+    # 128-wide network with 9 classes: render, per-sample field, training loss and all 22 gradients, like G11
     for tag, kw in (("h128", dict(hidden_size=128)), ("h64", dict(hidden_size=64, encoding_size=16, segmentation_outputs=7)),
-                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3))):
-        # A gradient is discontinuous in every ReLU gate, and a gate within rounding of zero (|gamma x_hat + beta| ~ 1e-7)
-        # falls on either side depending on the summation order of the LayerNorm that feeds it: the fixture takes the
-        # first seed whose training render has NO gate closer to zero than 2e-6 (read with forward hooks on the
-        # reference's LayerNorm modules), so that its gradients pin arithmetic, not coin flips.
-        for seed in range(21, 200):
-            torch.manual_seed(seed)
-            m = NeRF(**kw)
-            with torch.no_grad():
-                for slot in LINEAR_SLOTS:
-                    m.prediction_heads[slot].weight.mul_(2.0)
-            closest = []
-            hooks = [m.prediction_heads[i].register_forward_hook(lambda mod, inp, out: closest.append(float(out.abs().min())))
-                     for i in (1, 4, 7, 10, 13)]
-            torch.manual_seed(22)
-            u = torch.rand(64, 32)
-            noise = torch.randn(64, 31, 1)
-            target = torch.rand(64, 3)
-            # the reference's render_rays draws rand [N,S] then randn [N,S-1,1] (model.py:432, :652): replay them
-            torch.manual_seed(22)
-            pix, _ = m.render_rays(rays_o, rays_d, 32, randomly_sample=True, density_noise_std=0.5)
-            for hk in hooks:
-                hk.remove()
-            if min(closest) > 2e-6:
-                break
+                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3)),
+                    ("c1", dict(color_outputs=1)), ("c4", dict(color_outputs=4, hidden_size=128, segmentation_outputs=9))):
+        # The network of seed 21 as it comes: no search for a seed without borderline ReLU gates (round 5 did that — with
+        # hidden 64 this one has a gate 8.7e-8 from zero, which the kernels take on the other side).  The tests compare
+        # gate-aware instead (tests/gate_aware.py); the distance of the closest gate is recorded for information.
+        seed = 21
+        torch.manual_seed(seed)
+        m = NeRF(**kw)
+        with torch.no_grad():
+            for slot in LINEAR_SLOTS:
+                m.prediction_heads[slot].weight.mul_(2.0)
+        closest = []
+        hooks = [m.prediction_heads[i].register_forward_hook(lambda mod, inp, out: closest.append(float(out.abs().min())))
+                 for i in (1, 4, 7, 10, 13)]
+        torch.manual_seed(22)
+        u = torch.rand(64, 32)
+        noise = torch.randn(64, 31, 1)
+        target = torch.rand(64, kw.get("color_outputs", 3))
+        # the reference's render_rays draws rand [N,S] then randn [N,S-1,1] (model.py:432, :652): replay them
+        torch.manual_seed(22)
+        pix, _ = m.render_rays(rays_o, rays_d, 32, randomly_sample=True, density_noise_std=0.5)
+        for hk in hooks:
+            hk.remove()
         st = stages(m, rays_o, rays_d, 48)
         loss = ((pix - target.unsqueeze(1)) ** 2).mean()
         m.zero_grad()
         loss.backward()
-        save("g11_narrow_" + tag, rays_o=rays_o, rays_d=rays_d, u=u, noise=noise, noise_std=0.5, target=target,
+        save(("g12_colors_" if tag.startswith("c") else "g11_narrow_") + tag, rays_o=rays_o, rays_d=rays_d, u=u, noise=noise, noise_std=0.5, target=target,
              loss=loss.detach(), rgb=st["rgb"], seg_out=st["seg_out"], density=st["density"], color=st["color"],
              last_density=st["last_density"], init_seed=seed, closest_gate=min(closest),
              **{"param." + k: v for k, v in m.state_dict().items()},

@@ -187,7 +187,7 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
     "nerf_wgrad_h_kernel": (12, 0),
     "nerf_legacy_fwd_kernelILb1E": (76, 0),
     "nerf_legacy_fwd_h_kernelILb0E": (60, 0),
-    "nerf_legacy_fwd_h_kernelILb1E": (228, 7),
+    "nerf_legacy_fwd_h_kernelILb1E": (124, 1),
     "nerf_legacy_bwd_data_kernel": (272, 0),
     "nerf_legacy_bwd_data_h_kernel": (68, 0),
     "nerf_legacy_wgrad_h_kernel": (12, 0),
@@ -200,6 +200,7 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
 # grow or start being used unnoticed: (bytes, 0 scratch instructions).
 DEAD_FRAMES = {
     "nerf_render_fwd_kernelILb1ELb1ELb0ELi8E": 36,      # narrow split-precision training forward, three workgroups per CU
+    "nerf_render_fwd_kernelILb1ELb1ELb0ELi16E": 36,     # full-width split-precision training forward (230 registers)
 }
 
 

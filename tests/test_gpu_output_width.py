@@ -139,10 +139,18 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
     loss_r, ref = grads(torch.float32)
     _, exact = grads(torch.float64)
     noise_floor = max(rel_err(ref[k], exact[k]) for k in ref)
+    model.keep_workspace = True
     rgb, seg = model.render_rays(o.to(dev), d.to(dev), S, randomly_sample=True, density_noise_std=0.5,
                                  u=u.to(dev), noise=noise.to(dev))
     loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + (seg[:, 0] * w_seg.to(dev)).sum()
     loss.backward()
+    import gate_aware
+
+    def gated_loss(p, gates, record):
+        a, b = O.render_rays(p, cfg, o, d, S, u=u, noise=noise, density_noise_std=0.5, gates=gates, record=record)
+        return (a * w_rgb).sum() + (b * w_seg).sum()
+
+    gate_aware.check(model, params, n, S, gated_loss, tag=f"{shape} {train_precision}")
     assert abs(float(loss.detach()) - loss_r) <= 1e-4 * max(1.0, abs(loss_r))
     assert model.last_flat_grad.numel() == sum(p.numel() for p in model.parameters())
     if (hidden, enc) == (256, 32):
@@ -218,15 +226,18 @@ def test_layer_norm_with_a_large_common_bias(shape, strength, precision):
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("tag,kw", [("h128", dict(hidden_size=128)),
                                     ("h64", dict(hidden_size=64, encoding_size=16, segmentation_outputs=7)),
-                                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3))])
+                                    ("h40", dict(hidden_size=40, encoding_size=10, segmentation_outputs=3)),
+                                    ("c1", dict(color_outputs=1)),
+                                    ("c4", dict(color_outputs=4, hidden_size=128, segmentation_outputs=9))])
 def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
-    """Fixture G11 — the REFERENCE's own narrow networks (tests/golden/make_golden.py ran `nerf.model.NeRF(**kw)`): the
-    kernels instantiated at 8 / 4 register tiles per sample against the reference's render, per-sample field, training
-    loss and 22 gradients on the same rays and captured draws, not only against the oracle."""
+    """Fixtures G11 / G12 — the REFERENCE's own narrow networks and its networks with 1 and 4 color channels
+    (tests/golden/make_golden.py ran `nerf.model.NeRF(**kw)`): the kernels instantiated at 8 / 4 register tiles per
+    sample, and the run-time color count, against the reference's render, per-sample field, training loss and 22
+    gradients on the same rays and captured draws, not only against the oracle."""
     from conftest import load_golden, stable_rays
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")
-    g = load_golden("g11_narrow_" + tag)
+    g = load_golden(("g12_colors_" if tag.startswith("c") else "g11_narrow_") + tag)
     params = {k[6:]: v for k, v in g.items() if k.startswith("param.")}
     model = NeRF(**kw)
     model.load_state_dict(params)
@@ -242,6 +253,7 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
     assert (seg[:, 0].cpu() - g["seg_out"])[ok].abs().max() <= 1e-4
     assert (dens.cpu() - g["density"]).abs().max() <= 2e-5 * max(1.0, float(g["density"].abs().max()))
     assert (col.cpu() - g["color"]).abs().max() <= 2e-5 * max(1.0, float(g["color"].abs().max()))
+    model.keep_workspace = True
     pixels, _ = model.render_rays(o, d, 32, randomly_sample=True, density_noise_std=float(g["noise_std"]),
                                   u=g["u"].to(dev), noise=g["noise"].to(dev))
     loss = ((pixels - g["target"].to(dev).unsqueeze(1)) ** 2).mean()
@@ -253,9 +265,20 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
     O.training_loss(p64, cfg, g["rays_o"].double(), g["rays_d"].double(), 32, g["target"].double(), g["u"].double(),
                     g["noise"].double(), float(g["noise_std"])).backward()
     floor = max(rel_err(g["grad." + k], p64[k].grad.float()) for k, _ in model.named_parameters())
+    # gate-aware (tests/gate_aware.py): the fixture is the reference's network of seed 21 as it comes — with hidden 64
+    # one of its ReLU gates sits 8.7e-8 from zero and fell on the other side in the kernels (round 5 picked another
+    # seed for that; the generator no longer does).  The oracle on the KERNEL's gates pins the arithmetic, the flips
+    # are counted, and where there is none the reference's own gradients are held at the same bound.
+    import gate_aware
+    cfg32 = dict(O.default_config(), **kw)
+    flips, total, _, plain = gate_aware.check(
+        model, params, g["rays_o"].shape[0], 32,
+        lambda p, gates, record: O.training_loss(p, cfg32, g["rays_o"], g["rays_d"], 32, g["target"], g["u"], g["noise"],
+                                                 float(g["noise_std"]), gates=gates, record=record), tag=tag + " " + precision)
     for k, p in model.named_parameters():
+        assert rel_err(plain[k], g["grad." + k]) <= 1e-5, k          # the oracle IS the reference here
         e = rel_err(p.grad.cpu(), g["grad." + k])
-        assert e <= 5e-6 + 8 * floor, (k, e, floor)
+        assert e <= (1e-5 if flips == 0 else 5e-6 + 8 * floor + 2e-4 * flips), (k, e, floor, flips)
 
 
 def test_shapes_the_kernels_do_not_take_are_refused():

@@ -132,15 +132,21 @@ def test_statics():
 
 
 NARROW = {"h128": dict(hidden_size=128), "h64": dict(hidden_size=64, encoding_size=16, segmentation_outputs=7),
-          "h40": dict(hidden_size=40, encoding_size=10, segmentation_outputs=3)}
+          "h40": dict(hidden_size=40, encoding_size=10, segmentation_outputs=3),
+          # fixture G12: the reference's own networks with another color_outputs (nerf/model.py:471, :541-542, :591-592)
+          "c1": dict(color_outputs=1), "c4": dict(color_outputs=4, hidden_size=128, segmentation_outputs=9)}
+
+
+def fixture_of(tag):
+    return ("g12_colors_" if tag.startswith("c") else "g11_narrow_") + tag
 
 
 @pytest.mark.parametrize("tag", sorted(NARROW))
 def test_narrow_networks_match_the_reference(tag):
-    """Fixture G11: `NeRF(hidden_size=.., encoding_size=.., segmentation_outputs=..)` of the reference itself
-    (nerf/model.py:471-475) — render, per-sample field, training loss and all 22 gradients — pins the oracle at the
-    network shapes the narrow kernel instantiations are tested against."""
-    g = load_golden("g11_narrow_" + tag)
+    """Fixtures G11 / G12: `NeRF(hidden_size=.., encoding_size=.., segmentation_outputs=.., color_outputs=..)` of the
+    reference itself (nerf/model.py:471-475) — render, per-sample field, training loss and all 22 gradients — pins the
+    oracle at the network shapes the narrow kernel instantiations and the run-time color count are tested against."""
+    g = load_golden(fixture_of(tag))
     cfg = dict(O.default_config(), **NARROW[tag])
     params = {k[6:]: v for k, v in g.items() if k.startswith("param.")}
     with torch.no_grad():

@@ -14,24 +14,30 @@ def chunks_of(num_samples):
     return (num_samples - 1 + SAMPLES_PER_WAVE - 1) // SAMPLES_PER_WAVE
 
 
-def train_layout(n_rays, num_samples):
+def train_width(hidden_size):
+    """Features per saved x_hat / dY row: 128 when the network trains at 8 register tiles (hidden_size <= 128,
+    nerf_device.h: train_tiles), else 256."""
+    return 128 if hidden_size <= 128 else HIDDEN
+
+
+def train_layout(n_rays, num_samples, width=HIDDEN):
     """Offsets (in floats) of the saved tensors, like ``make_train_layout``: ``mp`` padded samples
-    = ceil4(n_rays) * chunks * 16; row tensors are [mp, features]."""
+    = ceil4(n_rays) * chunks * 16; row tensors are [mp, features] (``width`` for x_hat / dY)."""
     chunks = chunks_of(num_samples)
     mp = (n_rays + 3) // 4 * 4 * chunks * 16
-    lay, off = {"mp": mp, "chunks": chunks}, 0
+    lay, off = {"mp": mp, "chunks": chunks, "width": width}, 0
     lay["h"] = off
     off += mp * ENC_IN
     lay["dy"] = []
     for _ in range(5):
         lay["dy"].append(off)
-        off += mp * HIDDEN
+        off += mp * width
     lay["dy5"] = off
     off += mp * OUT_PAD
     lay["xhat"] = []
     for _ in range(5):
         lay["xhat"].append(off)
-        off += mp * HIDDEN
+        off += mp * width
     lay["rstd"] = []
     for _ in range(5):
         lay["rstd"].append(off)
@@ -62,10 +68,10 @@ def _row_major(workspace, lay, offset, width):
     i.e. element (sample s, feature f) of tile n at n * 4096 + (f >> 4) * 256 + ((f & 15) >> 2) * 64 + s * 4 + (f & 3)."""
     mp = lay["mp"]
     flat = workspace[offset:offset + mp * width]
-    if width != HIDDEN:
+    if width not in (HIDDEN, 128):
         return flat.view(mp, width)
-    tiles = flat.view(mp // 16, 16, 4, 16, 4)                # [n][T][g][s][r]
-    return tiles.permute(0, 3, 1, 2, 4).reshape(mp, HIDDEN)  # -> [n][s][T][g][r]
+    tiles = flat.view(mp // 16, width // 16, 4, 16, 4)       # [n][T][g][s][r]
+    return tiles.permute(0, 3, 1, 2, 4).reshape(mp, width)   # -> [n][s][T][g][r]
 
 
 def _rows(workspace, lay, offset, width, n_rays, num_samples):
@@ -84,16 +90,31 @@ def saved_h(workspace, n_rays, num_samples):
     return out
 
 
-def saved_xhat(workspace, layer, n_rays, num_samples):
-    """Normalised pre-affine activations of hidden layer ``layer`` (0..4): [n_rays, S-1, 256]."""
-    lay = train_layout(n_rays, num_samples)
-    return _rows(workspace, lay, lay["xhat"][layer], HIDDEN, n_rays, num_samples)
+def saved_xhat(workspace, layer, n_rays, num_samples, width=HIDDEN):
+    """Normalised pre-affine activations of hidden layer ``layer`` (0..4): [n_rays, S-1, width]."""
+    lay = train_layout(n_rays, num_samples, width)
+    return _rows(workspace, lay, lay["xhat"][layer], width, n_rays, num_samples)
 
 
-def saved_rstd(workspace, layer, n_rays, num_samples):
+def saved_rstd(workspace, layer, n_rays, num_samples, width=HIDDEN):
     """1 / sqrt(var + eps) of hidden layer ``layer``: [n_rays, S-1]."""
-    lay = train_layout(n_rays, num_samples)
+    lay = train_layout(n_rays, num_samples, width)
     return _rows(workspace, lay, lay["rstd"][layer], 1, n_rays, num_samples)[..., 0]
+
+
+def saved_gates(workspace, params, n_rays, num_samples):
+    """The five ReLU gates [n_rays, S-1, hidden_size] the training forward ran with AND its backward differentiates
+    through: both evaluate fma(x_hat, gamma, beta) > 0 on the saved x_hat (nerf_fused.h: normalize_tile,
+    nerf_backward_common.h: layer_norm_relu_bwd).  Evaluated here in float64, where the product of two fp32 values
+    is exact and the sum's sign is the fused operation's sign."""
+    hidden = params["prediction_heads.1.weight"].shape[0]
+    width = train_width(hidden)
+    gates = []
+    for layer, slot in enumerate((1, 4, 7, 10, 13)):
+        xhat = saved_xhat(workspace, layer, n_rays, num_samples, width)[..., :hidden].double().cpu()
+        z = xhat * params[f"prediction_heads.{slot}.weight"].double().cpu() + params[f"prediction_heads.{slot}.bias"].double().cpu()
+        gates.append(z > 0)
+    return gates
 
 
 # ---- the legacy 8 x 256 network's workspace (nerf_amd/csrc/nerf_legacy_layout.h: LegacyTrainLayout) ----------
