@@ -121,12 +121,17 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
     // nerf_composite_bwd_kernel (the suffix sum along the ray lives there), so the chunks of a ray
     // are independent here and a small batch still fills the chip
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
-        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
+        const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c   (uniform)
         {
-            const int64_t sp = tile * 16 + j;
+            // Addresses: the wave's 16-sample tile is wave-UNIFORM, so every saved row is (uniform 64-bit base of the tile,
+            // in scalar registers) + (this lane's constant 32-bit offset, taken where it is used: nerf_device.h:
+            // row_lane_offset) — as in the split-precision kernels below; per-lane 64-bit pointers to ten saved
+            // tensors were what this kernel parked in scratch across its layers
+            float* const ws_rows = ws + tile * kTileFloats;             // + L.xhat[l] / L.dy[l]: this tile's rows
+            const float* const ws_stat = ws + tile * 16;                // + L.rstd[l]: this tile's 16 scalars
             f32x4 dout[4];
             {
-                const float* drow = ws + ba.L.dy5 + sp * kOutPad + 4 * g;
+                const float* drow = ws + ba.L.dy5 + tile * (16 * kOutPad) + lane_offset((uint32_t)(j * kOutPad + 4 * g));
 #pragma unroll
                 for (int T = 0; T < 4; ++T) dout[T] = *(const f32x4*)(drow + T * 16);
             }
@@ -136,21 +141,18 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
             f32x4 xh[16];
             float rstd;
             layer_wide_v4<kStagesL5>(pipe, acc, dout,
-                                     BwdHook{turn, ws + ba.L.xhat[4] + tile_lane_base(sp, g),
-                                             ws + ba.L.rstd[4] + sp, xh, rstd});
+                                     BwdHookU{turn, ws_rows + ba.L.xhat[4], ws_stat + ba.L.rstd[4], xh, rstd});
             // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY ----
 #pragma unroll 1
             for (int L = 4; L >= 1; --L) {
-                layer_norm_relu_bwd(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
-                                    ws + ba.L.dy[L] + tile_lane_base(sp, g), gb + L * 2 * kHidden, turn, ba.inv_n);
+                layer_norm_relu_bwd<false, 16, true>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
+                                                     ws_rows + ba.L.dy[L], gb + L * 2 * kHidden, turn, ba.inv_n);
 #pragma unroll
                 for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
                 layer_wide<kStagesHidden>(pipe, acc, act,
-                                          BwdHook{turn, ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g),
-                                                  ws + ba.L.rstd[L - 1] + sp, xh, rstd});
+                                          BwdHookU{turn, ws_rows + ba.L.xhat[L - 1], ws_stat + ba.L.rstd[L - 1], xh, rstd});
             }
-            layer_norm_relu_bwd(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + tile_lane_base(sp, g),
-                                gb, turn, ba.inv_n);
+            layer_norm_relu_bwd<false, 16, true>(small, g, j, acc, act, xh, rstd, ws_rows + ba.L.dy[0], gb, turn, ba.inv_n);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

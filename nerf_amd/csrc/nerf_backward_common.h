@@ -40,7 +40,9 @@ struct GammaBetaTurn {
 // runs under this layer's MFMAs instead of in front of the LayerNorm arithmetic.  (Stage 1, not 0:
 // the loads then sit behind one stage's DMA in the vmcnt queue and the next stage's counted wait
 // retires them only after a whole stage of MFMAs.)
-template <int NT = 16>
+// kUniform: xhat_row / rstd_ptr are the wave's UNIFORM tile bases (scalar registers) and the lane's 32-bit offsets are
+// taken here (nerf_device.h: row_lane_offset) — no per-lane 64-bit pointer per saved tensor lives across the layers.
+template <int NT = 16, bool kUniform = false>
 struct BwdHookN {
     GammaBetaTurn& turn;
     const float* xhat_row;      // this lane's 4 features of register tile 0 (tile-major rows: nerf_device.h)
@@ -50,20 +52,22 @@ struct BwdHookN {
     __device__ __forceinline__ void operator()(int t) const {
         turn(t);
         if (t == 1) {
+            const float* row = kUniform ? xhat_row + row_lane_offset() : xhat_row;
 #pragma unroll
-            for (int T = 0; T < NT; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
-            rstd = *rstd_ptr;
+            for (int T = 0; T < NT; ++T) xh[T] = *(const f32x4*)(row + T * kTileT);
+            rstd = kUniform ? rstd_ptr[stat_lane_offset()] : *rstd_ptr;
         }
     }
 };
 typedef BwdHookN<16> BwdHook;
+typedef BwdHookN<16, true> BwdHookU;
 
 // LayerNorm + ReLU backward for hidden layer L on the register tile.
 //   in : acc = dL/dx (post-ReLU activations), saved x_hat tile and 1/std
 //   out: act = dL/dy (pre-LayerNorm output of the layer) = next B operands; also stored row-major
 //   kScaled (split-precision chain): acc holds dL/dx times the per-sample power of two `unscale`
 //   undoes (the B operands were scaled into the f16 range, the weights carry 2^kWScaleLog2)
-template <bool kScaled = false, int NT = 16>
+template <bool kScaled = false, int NT = 16, bool kUniformRow = false>
 __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g, int j,
                                                     f32x4 (&acc)[16], float (&act)[64],
                                                     const f32x4 (&xh)[16], float rstd,
@@ -139,7 +143,8 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             dy[r] = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
             act[4 * T + r] = dy[r];
         }
-        *(f32x4*)(dy_row + T * kTileT) = dy;
+        // (kUniformRow: dy_row is the wave's uniform tile base, the lane's offset is taken per store)
+        *(f32x4*)(dy_row + (kUniformRow ? row_lane_offset() : 0u) + T * kTileT) = dy;
     }
 }
 

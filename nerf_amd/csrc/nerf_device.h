@@ -116,6 +116,22 @@ __host__ __device__ inline int64_t tile_lane_base(int64_t sp, int g, int tile_fl
     return (sp >> 4) * tile_floats + tile_lane_word((int)(sp & 15), g);     // (tile_floats = 16 x row width)
 }
 
+// A lane's constant 32-bit offset behind an optimisation barrier, taken at every use: with a wave-uniform 64-bit base
+// (scalar registers) + this offset a saved row needs no per-lane 64-bit pointer — otherwise loop-invariant code
+// motion folds base + offset + tensor offset into one such pointer per saved tensor and parks them all across the
+// layers (the legacy training forward: 30 spilled address registers; nerf_backward.hip uses the same form).
+__device__ __forceinline__ uint32_t lane_offset(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// ... of this lane's f32x4 inside a tile-major 16-sample tile (nerf_device.h: tile_lane_word(j, g)) and inside a
+// [16] per-sample statistic, from the thread id alone (three integer operations per use, nothing kept)
+__device__ __forceinline__ uint32_t row_lane_offset() {
+    const uint32_t l = lane_offset(threadIdx.x);
+    return ((l >> 4) & 3u) * 64u + (l & 15u) * 4u;
+}
+__device__ __forceinline__ uint32_t stat_lane_offset() { return lane_offset(threadIdx.x) & 15u; }
+
 // The network's shape from an argument block (0 = the defaults 256 / 96), and what the LayerNorms need of it:
 // they divide their sums by hidden_size, not by the 256 features the kernels carry — the padded ones are exactly
 // zero before normalisation (nerf_layout.h: Shape) — and the second pass of the variance is written so that they add exactly nothing (nerf_fused.h).

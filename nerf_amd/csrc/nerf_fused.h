@@ -37,24 +37,8 @@ struct LazyNorm {
     const f32x4* bet;
     float* save_row;            // training: this lane's x_hat of register tile 0 (tile T at + kTileT T), else unused.
                                 // kOrderReluNorm (the legacy network's kernels): the wave's UNIFORM tile base, the
-                                // lane's offset inside the tile is taken at every use (row_lane_offset below)
+                                // lane's offset inside the tile is taken at every use (nerf_device.h: row_lane_offset)
 };
-
-// A lane's constant 32-bit offset behind an optimisation barrier, taken at every use: with a wave-uniform 64-bit base
-// (scalar registers) + this offset a saved row needs no per-lane 64-bit pointer — otherwise loop-invariant code
-// motion folds base + offset + tensor offset into one such pointer per saved tensor and parks them all across the
-// layers (the legacy training forward: 30 spilled address registers; nerf_backward.hip uses the same form).
-__device__ __forceinline__ uint32_t lane_offset(uint32_t v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-// ... of this lane's f32x4 inside a tile-major 16-sample tile (nerf_device.h: tile_lane_word(j, g)) and inside a
-// [16] per-sample statistic, from the thread id alone (three integer operations per use, nothing kept)
-__device__ __forceinline__ uint32_t row_lane_offset() {
-    const uint32_t l = lane_offset(threadIdx.x);
-    return ((l >> 4) & 3u) * 64u + (l & 15u) * 4u;
-}
-__device__ __forceinline__ uint32_t stat_lane_offset() { return lane_offset(threadIdx.x) & 15u; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 return r;
             };
             // training: the wave's UNIFORM tile bases of the saved rows (+ the tensor's offset), and this lane's 32-bit
-            // offsets inside a tile are taken where they are used (nerf_fused.h: row_lane_offset — no per-lane 64-bit
+            // offsets inside a tile are taken where they are used (nerf_device.h: row_lane_offset — no per-lane 64-bit
             // pointer lives across the layers)
             float* const xrow = kTrain ? ws + tile * kTileFloats : nullptr;         // (tile-major rows)
             float* const stat = kTrain ? ws + tile * 16 : nullptr;                  // (+ j)
@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                 }
                 float pos_act[64];
                 // (the encoders' per-lane constants — frequencies of lane group g — behind the optimisation barrier of
-                //  nerf_fused.h: lane_offset: hoisted out of the ray loop they are ten registers parked across every layer)
-                const int ge = kTrain ? (int)nerf_fused::lane_offset((uint32_t)g) : g;
+                //  nerf_device.h: lane_offset: hoisted out of the ray loop they are ten registers parked across every layer)
+                const int ge = kTrain ? (int)lane_offset((uint32_t)g) : g;
                 encode_position(ray, t0, la, ge, pos_act);
                 if (kTrain) {                     // both encodings as rows (un-scaled, as the fp32 forward saves them)
                     float dir_act[64];
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     {
                         const Ray ray = the_ray();
                         float enc[64];
-                        const int ge = kTrain ? (int)nerf_fused::lane_offset((uint32_t)g) : g;
+                        const int ge = kTrain ? (int)lane_offset((uint32_t)g) : g;
                         if (p == 1) encode_position(ray, *stash_t0, la, ge, enc, kX);
                         else encode_direction(ray, __builtin_sqrtf((ray.d[0] * ray.d[0] + ray.d[1] * ray.d[1]) + ray.d[2] * ray.d[2]),
                                               la, ge, enc, kX);

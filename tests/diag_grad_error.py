@@ -34,6 +34,32 @@ def main():
         loss.backward()
         return float(loss), {k: v.grad.double() for k, v in p.items() if v.grad is not None}
 
+    def oracle_dy(dtype):
+        """dL/dy of every hidden layer's pre-LayerNorm output y_L [n, S-1, 256], L = 0..4 (fp64 autograd)."""
+        import torch.nn.functional as F
+        p = {k: v.to(dtype) for k, v in params0.items()}
+        t = O.sample_t(p, 256, P.SAMPLES, u.to(dtype))
+        base_radius = 1 / ((3 ** 0.5) * cfg["focal_length"])
+        means, covs = O.frustum_gaussians(rays_o[idx].to(dtype), rays_d[idx].to(dtype), t, base_radius)
+        h = O.ipe_features(means, covs, -4, cfg["encoding_size"] // 2 - 4)
+        ys = []
+        x = F.linear(h, p["prediction_heads.0.weight"], p["prediction_heads.0.bias"])
+        for norm_slot, lin_slot in zip(O.NORM_IDS, O.LINEAR_IDS[1:]):
+            x.requires_grad_(True)
+            x.retain_grad()
+            ys.append(x)
+            x = F.relu(F.layer_norm(x, (x.shape[-1],), p[f"prediction_heads.{norm_slot}.weight"],
+                                    p[f"prediction_heads.{norm_slot}.bias"], 1e-5))
+            x = F.linear(x, p[f"prediction_heads.{lin_slot}.weight"], p[f"prediction_heads.{lin_slot}.bias"])
+        density, color, _ = x.split([1, 3, 50], dim=-1)
+        density = density + noise.to(dtype) * P.NOISE_STD
+        w = O.composite_weights(means, density)
+        rgb = (w * torch.sigmoid(color)).sum(dim=-2)
+        ((rgb.unsqueeze(1) - pixels[idx].to(dtype).unsqueeze(1)) ** 2).mean().backward()
+        return [y.grad for y in ys]
+
+    dy64 = oracle_dy(torch.float64)
+    dy32 = oracle_dy(torch.float32)
     l64, g64 = oracle(torch.float64)
     l32, g32 = oracle(torch.float32)
     runs = {"oracle fp32": g32}
@@ -42,11 +68,22 @@ def main():
         model.load_state_dict(params0)
         model = model.to(dev)
         model.train_precision = prec
+        model.keep_workspace = True
         pix, _ = model.render_rays(rays_o[idx].to(dev), rays_d[idx].to(dev), P.SAMPLES, randomly_sample=True,
                                    density_noise_std=P.NOISE_STD, u=u.to(dev), noise=noise.to(dev))
         loss = ((pix - pixels[idx].to(dev).unsqueeze(1)) ** 2).mean()
         loss.backward()
         runs["hip " + prec] = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+        import workspace_mirror as W
+        lay = W.train_layout(256, P.SAMPLES)
+        for L in range(5):
+            got = W._rows(model.last_workspace, lay, lay["dy"][L], 256, 256, P.SAMPLES).cpu().double()
+            e, e32 = got - dy64[L], dy32[L].double() - dy64[L]
+            per_sample = e.mean(-1)                       # an additive per-sample offset shows here
+            print(f"   dY[{L}] hip {prec}: max|dy| {float(dy64[L].abs().max()):.2e}  max|e| {float(e.abs().max()):.2e}  rms e "
+                  f"{float(e.pow(2).mean().sqrt()):.2e} (oracle fp32: {float(e32.pow(2).mean().sqrt()):.2e})  rms of the "
+                  f"per-sample MEAN error {float(per_sample.pow(2).mean().sqrt()):.2e} (oracle fp32: "
+                  f"{float(e32.mean(-1).pow(2).mean().sqrt()):.2e})")
         print(f"hip {prec}: loss {float(loss):.9f} (oracle fp64 {l64:.9f}, fp32 {l32:.9f})")
     print(f"{'tensor':32s} {'max|g|':>9s} " + " ".join(f"{n + ' max|e|':>22s} {'rms e':>9s} {'adam flips':>10s}" for n in runs))
     for k in g64:
