@@ -76,6 +76,21 @@ def main():
         runs["hip " + prec] = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
         import workspace_mirror as W
         lay = W.train_layout(256, P.SAMPLES)
+        # saved x_hat / gates against the fp64 oracle's
+        with torch.no_grad():
+            p64 = {k: v.double() for k, v in params0.items()}
+            t64 = O.sample_t(p64, 256, P.SAMPLES, u.double())
+            m64, c64 = O.frustum_gaussians(rays_o[idx].double(), rays_d[idx].double(), t64, 1 / ((3 ** 0.5) * cfg["focal_length"]))
+            h64 = O.ipe_features(m64, c64, -4, cfg["encoding_size"] // 2 - 4)
+            _, xh64, _ = O.mlp_stages(p64, h64)
+        for L, slot in enumerate((1, 4, 7, 10, 13)):
+            xk = W.saved_xhat(model.last_workspace, L, 256, P.SAMPLES).cpu().double()
+            ga, be = params0[f"prediction_heads.{slot}.weight"].double(), params0[f"prediction_heads.{slot}.bias"].double()
+            zk, z64 = xk * ga + be, xh64[L] * ga + be
+            flips = (zk > 0) != (z64 > 0)
+            print(f"   x_hat[{L}] hip {prec}: rms error {float((xk - xh64[L]).pow(2).mean().sqrt()):.2e}  max {float((xk - xh64[L]).abs().max()):.2e}; "
+                  f"{int(flips.sum())} gates differ from the fp64 oracle's, largest |z| among them "
+                  f"{float(z64[flips].abs().max()) if flips.any() else 0.0:.2e}")
         for L in range(5):
             got = W._rows(model.last_workspace, lay, lay["dy"][L], 256, 256, P.SAMPLES).cpu().double()
             e, e32 = got - dy64[L], dy32[L].double() - dy64[L]

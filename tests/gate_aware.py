@@ -15,12 +15,18 @@ import torch
 
 import workspace_mirror as W
 
-GRAD_BOUND = 1e-5            # measured <= 2e-6 (fp32) / 3e-6 (f16x3)
+GRAD_BOUND = 5e-6            # on top of the fp32 oracle's own distance from the fp64 oracle (same forced gates: arithmetic only)
 FLIP_BOUND = 1e-5            # share of gates that may differ from the oracle's own
 
 
 def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def caster(p):
+    """t -> t in the dtype of the parameter dict ``p`` (the oracle runs in fp32 and in fp64)."""
+    dtype = next(v for v in p.values()).dtype
+    return lambda t: t.to(dtype)
 
 
 def kernel_gates(model, params, n_rays, num_samples):
@@ -36,24 +42,29 @@ def oracle_gradients(params, loss_fn, gates=None, record=None, dtype=torch.float
 
 
 def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, flip_bound=FLIP_BOUND, tag=""):
-    """``loss_fn(p, gates, record)``: the oracle's loss on parameter dict ``p`` (its dtype), passing ``gates`` /
-    ``record`` through to oracle.nerf_oracle.mlp.  ``model`` holds the kernel's gradients (p.grad) of the same loss.
-    Returns (flips, total, worst error, the oracle's gradients on its OWN gates)."""
+    """``loss_fn(p, gates, record)``: the oracle's loss on parameter dict ``p`` (in ITS dtype: the function casts its
+    other inputs to ``next(iter(p.values())).dtype``), passing ``gates`` / ``record`` through to
+    oracle.nerf_oracle.mlp.  ``model`` holds the kernel's gradients (p.grad) of the same loss.  Every tensor must lie
+    within ``grad_bound`` + 4 x (the fp32 oracle's own distance from the fp64 oracle, both on the kernel's gates) of
+    the fp64 oracle on the kernel's gates, relative to its largest element.
+    Returns (flips, total, worst error, the fp32 oracle's gradients on its OWN gates)."""
     gates = kernel_gates(model, params, n_rays, num_samples)
     own = []
     _, plain = oracle_gradients(params, loss_fn, record=own)
-    _, ref = oracle_gradients(params, loss_fn, gates=gates)
+    _, ref32 = oracle_gradients(params, loss_fn, gates=gates)
+    _, ref64 = oracle_gradients(params, loss_fn, gates=gates, dtype=torch.float64)
     assert len(own) == len(gates) == 5 and all(a.shape == b.shape for a, b in zip(own, gates))
     flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
     total = sum(a.numel() for a in gates)
     assert flips <= max(flip_bound * total, 2), (flips, total)
     worst = 0.0
     for k, p in model.named_parameters():
-        assert p.grad is not None and p.grad.shape == ref[k].shape, k
-        e = rel_err(p.grad.cpu(), ref[k])
+        assert p.grad is not None and p.grad.shape == ref64[k].shape, k
+        floor = rel_err(ref32[k], ref64[k])
+        e = rel_err(p.grad.cpu(), ref64[k])
         worst = max(worst, e)
-        assert e <= grad_bound, (k, e)
-    print(f"[{tag}] worst relative gradient error on the kernel's gates {worst:.2e}; {flips} of {total} gates differ from "
-          f"the oracle's own (against the oracle on ITS gates: "
-          f"{max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
+        assert e <= grad_bound + 4.0 * floor, (k, e, floor)
+    print(f"[{tag}] worst relative gradient error on the kernel's gates {worst:.2e} (fp32 oracle, same gates: "
+          f"{max(rel_err(ref32[k], ref64[k]) for k in ref64):.2e}); {flips} of {total} gates differ from the oracle's own "
+          f"(against the oracle on ITS gates: {max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
     return flips, total, worst, plain

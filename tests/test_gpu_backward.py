@@ -87,10 +87,12 @@ def test_training_step_vs_reference(dev, name, scale):
     import gate_aware
     flips, total, _, _ = gate_aware.check(
         model, golden_params(scale), g["rays_o"].shape[0], 64,
-        lambda p, gates, record: O.training_loss(p, CFG, g["rays_o"], g["rays_d"], 64, g["target"], g["u"], g["noise"],
-                                                 float(g["noise_std"]), gates=gates, record=record), tag=name)
+        lambda p, gates, record: O.training_loss(
+            p, CFG, *(gate_aware.caster(p)(g[k]) for k in ("rays_o", "rays_d")), 64,
+            *(gate_aware.caster(p)(g[k]) for k in ("target", "u", "noise")), float(g["noise_std"]), gates=gates,
+            record=record), tag=name)
     if flips == 0:
-        assert worst <= 1e-5, worst
+        assert worst <= 5e-6 + 8 * noise_floor, worst
     # (with the split-precision forward the saved activations differ from the reference's by ~3e-6,
     #  which is enough to flip a gate or two even here: the noise-floor bound above applies)
     # RGB-only loss: the 50 segmentation rows of the last Linear get exactly zero gradient
@@ -130,11 +132,14 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
     loss.backward()
     assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-4 * max(1.0, abs(float(loss_r.detach())))
 
-    def gated_loss(p, gates, record):
-        a, b = O.render_rays(p, CFG, o, d, num_samples, u=u, noise=noise, density_noise_std=0.5, gates=gates, record=record)
-        return (a * w_rgb).sum() + ((b * w_seg).sum() if with_seg else 0.0)
-
     import gate_aware
+
+    def gated_loss(p, gates, record):
+        c = gate_aware.caster(p)
+        a, b = O.render_rays(p, CFG, c(o), c(d), num_samples, u=c(u), noise=c(noise), density_noise_std=0.5, gates=gates,
+                             record=record)
+        return (a * c(w_rgb)).sum() + ((b * c(w_seg)).sum() if with_seg else 0.0)
+
     gate_aware.check(model, params, n_rays, num_samples, gated_loss, tag=f"{n_rays}x{num_samples}")
     def loss64(p):
         a, b = O.render_rays(p, CFG, o.double(), d.double(), num_samples, u=u.double(),

@@ -147,8 +147,9 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
     import gate_aware
 
     def gated_loss(p, gates, record):
-        a, b = O.render_rays(p, cfg, o, d, S, u=u, noise=noise, density_noise_std=0.5, gates=gates, record=record)
-        return (a * w_rgb).sum() + (b * w_seg).sum()
+        c = gate_aware.caster(p)
+        a, b = O.render_rays(p, cfg, c(o), c(d), S, u=c(u), noise=c(noise), density_noise_std=0.5, gates=gates, record=record)
+        return (a * c(w_rgb)).sum() + (b * c(w_seg)).sum()
 
     gate_aware.check(model, params, n, S, gated_loss, tag=f"{shape} {train_precision}")
     assert abs(float(loss.detach()) - loss_r) <= 1e-4 * max(1.0, abs(loss_r))
@@ -273,8 +274,10 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
     cfg32 = dict(O.default_config(), **kw)
     flips, total, _, plain = gate_aware.check(
         model, params, g["rays_o"].shape[0], 32,
-        lambda p, gates, record: O.training_loss(p, cfg32, g["rays_o"], g["rays_d"], 32, g["target"], g["u"], g["noise"],
-                                                 float(g["noise_std"]), gates=gates, record=record), tag=tag + " " + precision)
+        lambda p, gates, record: O.training_loss(
+            p, cfg32, *(gate_aware.caster(p)(g[k]) for k in ("rays_o", "rays_d")), 32,
+            *(gate_aware.caster(p)(g[k]) for k in ("target", "u", "noise")), float(g["noise_std"]), gates=gates,
+            record=record), tag=tag + " " + precision)
     for k, p in model.named_parameters():
         assert rel_err(plain[k], g["grad." + k]) <= 1e-5, k          # the oracle IS the reference here
         e = rel_err(p.grad.cpu(), g["grad." + k])
