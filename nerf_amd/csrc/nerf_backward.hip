@@ -681,7 +681,10 @@ __global__ void nerf_grad_reduce_kernel(const BwdArgs ba) {
     if (which >= 2) return;                       // gamma / beta: the blocks behind
     int so;
     if (which == 0) {          // (row, column) of the tensor -> its place in the full-width slab
-        if (L == 0) so = kSlabW0 + (idx / sh.enc_in) * kEncIn + layer0_kernel_column(idx % sh.enc_in, sh.scales());
+        // (layer 0's columns in the order of the forward that saved the inputs: the narrow kernels spread the scales
+        //  the network has over the lane groups, nerf_layout.h: scales_per_group)
+        if (L == 0) so = kSlabW0 + (idx / sh.enc_in) * kEncIn +
+                         layer0_kernel_column(idx % sh.enc_in, sh.scales(), train_tiles(sh.hidden) == 8 ? scales_per_group(sh.scales()) : 4);
         else if (L == 5) so = kSlabW5 + slot_of_row(idx / sh.hidden, sh) * kHidden + idx % sh.hidden;
         else so = kSlabWh + (L - 1) * kHidden * kHidden + (idx / sh.hidden) * kHidden + idx % sh.hidden;
     } else {

@@ -857,6 +857,35 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         act[12 + p] = damp * sin_reduced(y + half_pi);
     }
 }
+// The narrow kernels' form: `per` scales per lane group (nerf_layout.h: scales_per_group — the scales the network HAS,
+// spread over the four lane groups), the pairs of the scales beyond them skipped wave-uniformly and left 0 (their
+// columns of layer 0 are zero in the narrow images): a network of encoding_size 16 evaluates 6 of the 12 pairs.
+__device__ __forceinline__ void encode_n(const Gaussian& gs, int g, int per, float (&act)[64]) {
+#pragma clang fp contract(off)
+    const float base = __builtin_ldexpf(1.0f, per * g - 4);     // 2^(per g - 4): scales per g .. of -4..11
+    const float half_pi = 1.5707963267948966f;
+#pragma unroll
+    for (int local = 0; local < 4; ++local) {
+        // (results in scalars that merge behind the branch: written into act[] inside it, the array stays in memory)
+        float sn[3] = {0.f, 0.f, 0.f}, cs[3] = {0.f, 0.f, 0.f};
+        if (local < per) {                                      // (per: a launch constant)
+            const float scale = base * (float)(1 << local);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float y = gs.mean[c] * scale;
+                const float yv = gs.cov[c] * (scale * scale);
+                const float damp = expf(-0.5f * yv);
+                sn[c] = damp * sin_reduced(y);
+                cs[c] = damp * sin_reduced(y + half_pi);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            act[3 * local + c] = sn[c];
+            act[12 + 3 * local + c] = cs[c];
+        }
+    }
+}
 
 // distance between the means of consecutive Gaussians (nerf/model.py:462-464)
 __device__ __forceinline__ float mean_distance(const Gaussian& a, const Gaussian& b) {

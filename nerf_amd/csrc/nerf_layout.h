@@ -235,17 +235,23 @@ __host__ __device__ inline int layer0_source_feature(int t, int g, int r) {
 }
 // The same slot for a network with `scales` <= 16 scales (encoding_size = 2 scales): its source feature in the
 // reference's [sin: scales x 3 | shifted: scales x 3] order, or -1 for a scale the network does not have.
-__host__ __device__ inline int layer0_source_feature(int t, int g, int r, int scales) {
+// `per` = scales per lane group: lane group g evaluates scales per g .. per g + per - 1 in its first 3 per (scale,
+// coordinate) pairs.  4 for the full-width kernels (whatever the network: their front end always evaluates 16 scales);
+// the NARROW kernels (nerf_layout.h: Narrow<NT>), whose frame time is front-end VALU work, spread the scales a
+// network HAS over the four lane groups — scales_per_group — and skip the pairs beyond them.
+__host__ __device__ inline int scales_per_group(int scales) { return (scales + 3) / 4; }
+__host__ __device__ inline int layer0_source_feature(int t, int g, int r, int scales, int per = 4) {
     const int q = 4 * t + r;
     const int part = q / 12, p = q % 12;
-    const int scale = 4 * g + p / 3, coord = p % 3;
-    return scale < scales ? part * 3 * scales + 3 * scale + coord : -1;
+    const int local = p / 3, coord = p % 3;
+    const int scale = per * g + local;
+    return local < per && scale < scales ? part * 3 * scales + 3 * scale + coord : -1;
 }
 // ... and back: kernel column (16 t + 4 g + r) of source feature f
-__host__ __device__ inline int layer0_kernel_column(int f, int scales) {
+__host__ __device__ inline int layer0_kernel_column(int f, int scales, int per = 4) {
     const int part = f / (3 * scales), rem = f % (3 * scales);
     const int scale = rem / 3, coord = rem % 3;
-    const int g = scale / 4, q = part * 12 + (scale % 4) * 3 + coord;
+    const int g = scale / per, q = part * 12 + (scale % per) * 3 + coord;
     return 16 * (q / 4) + 4 * g + (q % 4);
 }
 

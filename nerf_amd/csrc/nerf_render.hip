@@ -33,6 +33,7 @@ struct KernelArgs {
     int64_t groups;             // ceil(n_rays / 4)
     TrainLayout save;           // offsets into a.train_workspace (training forward only)
     NormDivisor norm;           // 1 / hidden_size and the padded feature count of the LayerNorms (nerf_layout.h: Shape)
+    int32_t enc_per;            // narrow kernels: encoding scales per lane group (nerf_layout.h: scales_per_group)
 };
 
 typedef WeightPipe<kNumStages> FwdPipe;
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void
             }
             {
                 float feat[64];
-                encode(gs, g, feat);
+                if constexpr (NT == 16) encode(gs, g, feat);
+                else encode_n(gs, g, ka.enc_per, feat);
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t)
                     X[t] = f32x4{feat[4 * t], feat[4 * t + 1], feat[4 * t + 2], feat[4 * t + 3]};
@@ -645,8 +647,9 @@ struct PackArgs {
     int32_t hidden, enc_in;     // H and 6 x scales of the source tensors; the images are zero beyond them (nerf_layout.h)
     // element (out, in) of the source matrices, 0 in the padding: layer 0 by kernel slot (t, g, r), the hidden
     // layers L = 1..4, the last layer; element f of a per-feature vector (bias / gamma / beta: tensor index)
-    __device__ __forceinline__ float w0(int out, int t, int g, int r) const {
-        const int src = layer0_source_feature(t, g, r, enc_in / 6);
+    // (per: scales per lane group of the image being written — 4 in the full-width images, scales_per_group in the narrow ones)
+    __device__ __forceinline__ float w0(int out, int t, int g, int r, int per = 4) const {
+        const int src = layer0_source_feature(t, g, r, enc_in / 6, per);
         return out < hidden && src >= 0 ? p[0][out * enc_in + src] : 0.f;
     }
     __device__ __forceinline__ float wh(int L, int out, int in) const {
@@ -739,7 +742,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
             const int tl = jj >> 2, r = jj & 3;
             float w = 0.f;
             if (stage < 3) {
-                w = pa.w0(16 * pair + row, 2 * stage + tl, kg, r);
+                w = pa.w0(16 * pair + row, 2 * stage + tl, kg, r, scales_per_group(pa.enc_in / 6));
             } else if (stage < 3 + 16) {
                 const int L = 1 + (stage - 3) / 4, m = (stage - 3) % 4;
                 w = pa.wh(L, 16 * pair + row, 32 * m + 16 * tl + 4 * kg + r);
@@ -786,7 +789,7 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         const int sh = eight ? Narrow<8>::kStagesHid : Narrow<4>::kStagesHid;
         if (stage < s0) {                                           // layer 0: quads numbered k-group * NT + out tile
             const int qq = stage * 16 + quad, k = qq / nt, T = qq % nt;
-            v = k < kStagesL0 ? pa.w0(16 * T + row, k, g, r) : 0.f;
+            v = k < kStagesL0 ? pa.w0(16 * T + row, k, g, r, scales_per_group(pa.enc_in / 6)) : 0.f;
         } else if (stage < s0 + 4 * sh) {                           // layers 1..4
             const int L = 1 + (stage - s0) / sh;
             const int qq = ((stage - s0) % sh) * 16 + quad, k = qq / nt, T = qq % nt;
@@ -1024,6 +1027,7 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     const int tt = train_tiles(shape_of(a).hidden);       // training: 8 or 16 register tiles per sample
     ka.save = make_train_layout(a.n_rays, ka.chunks, 16 * tt);
     ka.norm = norm_divisor(shape_of(a).hidden);
+    ka.enc_per = scales_per_group(shape_of(a).scales());
     if (a.precision != NERF_HIP_PRECISION_FP32 && a.precision != NERF_HIP_PRECISION_F16X3)
         return nerf_common::fail(NERF_HIP_EINVAL, "render_forward: unknown precision");
     if (train && a.out_t != nullptr)

@@ -15,6 +15,7 @@ r = bench.legacy_workload_timing(dev, steps=3, warmup=1)
 t = bench.legacy_train_step_timing(dev, train_precision="f16x3")
 m = {p: bench.train_step_timing(dev, train_precision=p)["ms_per_step"] for p in ("fp32", "f16x3")}
 print(json.dumps({"fp32": r["kernel_ms"], "f16x3": r["other_precision"]["kernel_ms"], "train_f16x3": t["ms_per_step"],
+                  "train_f16x3_fwd_kernel": t["kernels_ms"]["forward"], "train_f16x3_dgrad_kernel": t["kernels_ms"]["data_gradient"],
                   "main_train_fp32": m["fp32"], "main_train_f16x3": m["f16x3"]}))
 """ % ROOT
 res = {l: [] for l in libs}
@@ -28,5 +29,6 @@ for r in range(rounds):
             sys.exit(1)
         res[l].append(json.loads(lines[-1]))
 for l, v in res.items():
-    for key in ("fp32", "f16x3", "train_f16x3", "main_train_fp32", "main_train_f16x3"):
-        print(f"{l:22s} {key:18s} ms: " + " ".join(f"{x[key]:.2f}" for x in v) + f"   min {min(x[key] for x in v):.2f}")
+    for key in ("fp32", "f16x3", "train_f16x3", "train_f16x3_fwd_kernel", "train_f16x3_dgrad_kernel", "main_train_fp32",
+                "main_train_f16x3"):
+        print(f"{l:28s} {key:24s} ms: " + " ".join(f"{x[key]:.3f}" for x in v) + f"   min {min(x[key] for x in v):.3f}")
