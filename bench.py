@@ -958,6 +958,8 @@ def main():
             line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
             line["train_step_hidden128"] = train_step_timing(dev, hidden=128)
             line["train_step_hidden128_f16x3"] = train_step_timing(dev, hidden=128, train_precision="f16x3")
+            # hidden_size <= 64 trains at 8 register tiles too (no 4-tile weight gradient): 128's cost
+            line["train_step_hidden64_enc16"] = train_step_timing(dev, hidden=64, enc=16)
             line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
             line["legacy_train_step"] = legacy_train_step_timing(dev)

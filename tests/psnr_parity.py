@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--tag", default="cpu_mt")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--own-draws", action="store_true")
+    ap.add_argument("--seeds", type=int, default=3, help="part rng: seeds per side")
+    ap.add_argument("--first-seed", type=int, default=0)
     ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r06_psnr_parity.json"))
     args = ap.parse_args()
     if args.cmd == "scene":
@@ -276,9 +278,15 @@ def main():
                                  ("hip_f16x3_graph", "f16x3", True), ("hip_fp32_graph", "fp32", True)):
             hip_run(args.out, tag, args.steps, args.every, args.seed, prec, graph, "captured")
     else:
-        kids = [spawn_oracle(args.out, f"cpu_rng{s}", 5, args.steps, args.every, 100 + s, True) for s in range(3)]
-        for s in range(3):
+        seeds = list(range(args.first_seed, args.first_seed + args.seeds))
+        kids = [spawn_oracle(args.out, f"cpu_rng{s}", 5, args.steps, args.every, 100 + s, True) for s in seeds[:3]]
+        for s in seeds:
             hip_run(args.out, f"hip_philox{s}", args.steps, args.every, 200 + s, "f16x3", True, "philox")
+        for i in range(3, len(seeds), 3):                     # three oracle runs at a time (5 threads each)
+            while any(k.poll() is None for k in kids):
+                time.sleep(10)
+                print("waiting for the oracle runs", flush=True)
+            kids += [spawn_oracle(args.out, f"cpu_rng{s}", 5, args.steps, args.every, 100 + s, True) for s in seeds[i:i + 3]]
     while any(k.poll() is None for k in kids):            # a line a minute: the box takes silence for a hang
         time.sleep(30)
         tails = []
