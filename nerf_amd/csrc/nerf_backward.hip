@@ -170,8 +170,35 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
 // 2 stages for layer 5, 4 per hidden layer).  The wave-ordered gamma / beta adds of a layer ride on the four stage
 // barriers of the hidden loop that follows it; layer 0's have no such loop behind them (the next item opens with
 // the two-stage layer-5 loop), so they take their turns at the end of the item, a barrier apart.
-__global__ __launch_bounds__(256, 2) void nerf_bwd_data_n8_kernel(const BwdArgs ba) {
-    constexpr int NT = 8, kTileN = 256 * NT;
+// NT = 4 (hidden_size <= 64, round 6: nerf_device.h: train_compute_tiles): the chain COMPUTES at 4 register tiles on
+// the image at kNarrowBwd4Offset (one stage per layer), the rows it reads and writes stay 128 wide — it loads tiles
+// 0 .. 3 of x_hat and writes tiles 4 .. 7 of dY as zeros for the 8-tile weight gradient.  A one-stage loop has one
+// barrier, so EVERY layer's gamma / beta partials take their four turns behind explicit barriers, and the next
+// LayerNorm backward's x_hat is fetched at stage 0.
+template <int NT>
+struct NarrowBwdImage {
+    static constexpr int kStages = NT == 8 ? kNarrowBwd8Stages : kNarrowBwd4Stages;
+    static constexpr int kOffset = NT == 8 ? kNarrowBwd8Offset : kNarrowBwd4Offset;
+};
+// (the hook of the 4-tile chain: loads at stage 0 — there is no stage 1 — and no turns: they are taken explicitly)
+struct BwdHookLoad4 {
+    const float* xhat_row;
+    const float* rstd_ptr;
+    f32x4 (&xh)[16];
+    float& rstd;
+    __device__ __forceinline__ void operator()(int t) const {
+        if (t == 0) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) xh[T] = *(const f32x4*)(xhat_row + T * kTileT);
+            rstd = *rstd_ptr;
+        }
+    }
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void nerf_bwd_data_n_kernel(const BwdArgs ba) {
+    static_assert(NT == 8 || NT == 4, "narrow data gradient: 8 or 4 register tiles");
+    constexpr int kTileN = 256 * 8;               // floats of a saved 16-sample tile: the rows are 128 wide at either NT
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ba.a;
     const int lane = threadIdx.x & 63;
@@ -186,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n8_kernel(const BwdArgs 
     }
     const float* small = (const float*)(smem + kRingBytes);
 
-    WeightPipe<kNarrowBwd8Stages> pipe;
-    pipe.init(a.packed + kNarrowBwd8Offset, smem, wave, lane);
+    WeightPipe<NarrowBwdImage<NT>::kStages> pipe;
+    pipe.init(a.packed + NarrowBwdImage<NT>::kOffset, smem, wave, lane);
     pipe.issue();
     pipe.issue();
     __syncthreads();
@@ -198,6 +225,19 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n8_kernel(const BwdArgs 
     turn.dst = gb + 16 * j + 4 * g;
     turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
     turn.wave = wave;
+    auto take_turns = [&]() {                     // the four waves add their partials in wave order, a barrier apart
+        for (int t = 0; t < kWavesPerWg; ++t) {
+            __syncthreads();
+            turn(t);
+        }
+        turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto zero_upper = [&](float* row) {           // NT = 4: tiles 4 .. 7 of a 128-wide saved row
+        if (NT == 4) {
+#pragma unroll
+            for (int T = 4; T < 8; ++T) *(f32x4*)(row + T * kTileT) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
 
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
@@ -210,31 +250,42 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n8_kernel(const BwdArgs 
                 act[4 * T] = d.x, act[4 * T + 1] = d.y, act[4 * T + 2] = d.z, act[4 * T + 3] = d.w;
             }
         }
-        // ---- layer 5: dX = W5^T dOut (4 k-groups of padded outputs x 8 in tiles: 2 stages) ----
+        // ---- layer 5: dX = W5^T dOut (4 k-groups of padded outputs x NT in tiles) ----
 #pragma unroll
         for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 xh[16];
         float rstd;
-        layer_wide_n<NT, 4>(pipe, acc, act,
-                            BwdHookN<NT>{turn, ws + ba.L.xhat[4] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[4] + sp, xh, rstd});
-        // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY (8 k-groups x 8 in tiles: 4 stages) ----
+        if constexpr (NT == 8)
+            layer_wide_n<NT, 4>(pipe, acc, act,
+                                BwdHookN<NT>{turn, ws + ba.L.xhat[4] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[4] + sp, xh, rstd});
+        else
+            layer_wide_n<NT, 4>(pipe, acc, act,
+                                BwdHookLoad4{ws + ba.L.xhat[4] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[4] + sp, xh, rstd});
+        // ---- layers 4..1: LayerNorm/ReLU backward, then dX = W^T dY (NT k-groups x NT in tiles) ----
 #pragma unroll 1
         for (int L = 4; L >= 1; --L) {
-            layer_norm_relu_bwd<false, NT>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd,
-                                           ws + ba.L.dy[L] + tile_lane_base(sp, g, kTileN), gb + L * 2 * kHidden, turn, ba.inv_n);
+            float* const dyrow = ws + ba.L.dy[L] + tile_lane_base(sp, g, kTileN);
+            layer_norm_relu_bwd<false, NT>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd, dyrow, gb + L * 2 * kHidden, turn,
+                                           ba.inv_n);
+            zero_upper(dyrow);
+            if (NT == 4) take_turns();
 #pragma unroll
             for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
-            layer_wide_n<NT, NT>(pipe, acc, act,
-                                 BwdHookN<NT>{turn, ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[L - 1] + sp,
-                                              xh, rstd});
+            if constexpr (NT == 8)
+                layer_wide_n<NT, NT>(pipe, acc, act,
+                                     BwdHookN<NT>{turn, ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[L - 1] + sp,
+                                                  xh, rstd});
+            else
+                layer_wide_n<NT, NT>(pipe, acc, act,
+                                     BwdHookLoad4{ws + ba.L.xhat[L - 1] + tile_lane_base(sp, g, kTileN), ws + ba.L.rstd[L - 1] + sp,
+                                                  xh, rstd});
         }
-        layer_norm_relu_bwd<false, NT>(small, g, j, acc, act, xh, rstd, ws + ba.L.dy[0] + tile_lane_base(sp, g, kTileN), gb, turn,
-                                       ba.inv_n);
-        for (int t = 0; t < kWavesPerWg; ++t) {       // layer 0's partials, in wave order
-            __syncthreads();
-            turn(t);
+        {
+            float* const dyrow = ws + ba.L.dy[0] + tile_lane_base(sp, g, kTileN);
+            layer_norm_relu_bwd<false, NT>(small, g, j, acc, act, xh, rstd, dyrow, gb, turn, ba.inv_n);
+            zero_upper(dyrow);
         }
-        turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
+        take_turns();                             // layer 0's partials (NT = 8: the only ones without a loop behind them)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -399,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_kernel(const BwdArgs b
 // 128 wide (a wave's 16-sample tile = 8 KiB), the transposed f16-pair image of nerf_layout.h: kNarrowBwdH8Offset
 // (2 stages for layer 5, 4 per hidden layer), 8 x_hat loads + 1 and 8 dY saves per layer in the hand-overs' counts.
 // Layer 0's gamma / beta partials take their turns at the end of the item (the two-stage layer-5 loop that opens the
-// next item has only two barriers), as in nerf_bwd_data_n8_kernel.
+// next item has only two barriers), as in nerf_bwd_data_n_kernel<8>.
 constexpr int kYoungerL5N8 = 9, kYoungerHiddenN8 = 17;
 __global__ __launch_bounds__(256, 2) void nerf_bwd_data_h_n8_kernel(const BwdArgs ba) {
     constexpr int NT = 8;
@@ -777,10 +828,15 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad_h);
     if (rc) return rc;
-    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0, done_data_h_n8 = 0, done_wgrad_h_n8 = 0;
+    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0, done_data_h_n8 = 0, done_wgrad_h_n8 = 0, done_data_n4 = 0;
+    const int ct = train_compute_tiles(shape_of(a).hidden, half);     // 4: hidden_size <= 64 in fp32 arithmetic
+    if (ct == 4) {
+        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n_kernel<4>, kBwdLdsBytes, device, &done_data_n4);
+        if (rc) return rc;
+    }
     if (tt == 8) {
         rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_h_n8_kernel, kBwdLdsBytes + 32, device, &done_data_h_n8)
-                  : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n8_kernel, kBwdLdsBytes, device, &done_data_n8);
+                  : nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n_kernel<8>, kBwdLdsBytes, device, &done_data_n8);
         if (rc) return rc;
         rc = half ? nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_h_n8)
                   : nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n8_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n8);
@@ -803,7 +859,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_DATA_GRADIENT);
         if (half && tt == 8) hipLaunchKernelGGL(nerf_bwd_data_h_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
         else if (half) hipLaunchKernelGGL(nerf_bwd_data_h_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes + 32, st, ba);
-        else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n8_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+        else if (ct == 4) hipLaunchKernelGGL(nerf_bwd_data_n_kernel<4>, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
+        else if (tt == 8) hipLaunchKernelGGL(nerf_bwd_data_n_kernel<8>, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
         else hipLaunchKernelGGL(nerf_bwd_data_kernel, dim3((unsigned)grid), dim3(256), kBwdLdsBytes, st, ba);
     }
     const int wgrad_jobs = 6;

@@ -93,6 +93,10 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
 // register tiles per sample the TRAINING kernels of a launch run at: 8 for a narrow network (hidden_size <= 128;
 // <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator tiles), else 16
 __host__ __device__ inline int train_tiles(int hidden) { return hidden <= 128 ? 8 : 16; }      // (both arithmetics)
+// ... and the register tiles the training forward and the data gradient COMPUTE at: 4 for hidden_size <= 64 in fp32
+// arithmetic (a quarter of the MFMAs; tiles 4 .. 7 of the 128-wide saved rows are written as zeros for the weight
+// gradient, whose products with them land in rows / columns the reduce kernel never copies), else train_tiles
+__host__ __device__ inline int train_compute_tiles(int hidden, bool half) { return !half && hidden <= 64 ? 4 : train_tiles(hidden); }
 
 // Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the
 // [16 samples][256 features] tile of a wave is stored as its 16 register tiles T, 1 KiB each — so one vector-memory

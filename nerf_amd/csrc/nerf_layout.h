@@ -125,7 +125,13 @@ constexpr int kNarrowH8Offset = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFl
 // element (lane (row, kg), jj) = 2^kWScaleLog2 * W[32 m + 16 (jj >> 2) + 4 kg + (jj & 3)][16 i + row]
 constexpr int kNarrowBwdH8Stages = 2 + 4 * 4;
 constexpr int kNarrowBwdH8Offset = kNarrowH8Offset + kNarrowH8Stages * kStageFloats;
-constexpr int kPackedFloats = kNarrowBwdH8Offset + kNarrowBwdH8Stages * kStageFloats;
+// ... and the transposed fp32 image at 4 register tiles (hidden_size <= 64 training in fp32 arithmetic: forward and
+// data gradient COMPUTE at 4 tiles, the saved rows stay 128 wide for the 8-tile weight gradient): quads numbered
+// k-group * 4 + in tile: layer 5 = 4 k-groups of padded outputs x 4 in tiles = 1 stage, layers 4, 3, 2, 1 = 4 k-groups
+// x 4 in tiles = 1 stage each
+constexpr int kNarrowBwd4Stages = 1 + 4;
+constexpr int kNarrowBwd4Offset = kNarrowBwdH8Offset + kNarrowBwdH8Stages * kStageFloats;
+constexpr int kPackedFloats = kNarrowBwd4Offset + kNarrowBwd4Stages * kStageFloats;
 static_assert(kWideFloats % 4 == 0, "narrow images start 16-byte aligned");
 // register tiles a network of `hidden` features needs, rounded up to an instantiated width
 __host__ __device__ inline int tiles_for(int hidden) { return hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16); }

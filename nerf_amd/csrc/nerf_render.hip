@@ -357,8 +357,10 @@ constexpr bool three_per_cu() { return NT < 16 && !kPerSample; }
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
 __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
-    static_assert(NT != 4 || (!kTrain && !kHalf), "4 register tiles: fp32 inference only (training and the "
-                                                  "split-precision arithmetic run at 8 or 16)");
+    static_assert(NT != 4 || !kHalf, "4 register tiles: fp32 arithmetic only (the split-precision arithmetic runs at 8 or 16)");
+    // saved x_hat rows of a training forward: 128 wide for the narrow networks at EITHER compute width (the weight
+    // gradient runs at 8 register tiles): a 4-tile forward writes tiles 4 .. 7 as zeros
+    constexpr int kSaveTiles = NT == 4 ? 8 : NT;
     typedef Narrow<NT> N;
     constexpr int kDepth = three_per_cu<kPerSample, NT>() ? 2 : 3;
     constexpr int kRingB = kDepth * kStageBytes, kLdsB = kRingB + kSmallLdsBytes;
@@ -446,7 +448,13 @@ __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void
 #pragma unroll
                 for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
-            float* const xrow = kTrain ? ws + tile_lane_base(sp, g, 256 * NT) : nullptr;     // + ka.save.xhat[L] (tile-major)
+            float* const xrow = kTrain ? ws + tile_lane_base(sp, g, 256 * kSaveTiles) : nullptr;     // + ka.save.xhat[L] (tile-major)
+            if (kTrain && NT == 4) {
+#pragma unroll
+                for (int L = 0; L < 5; ++L)
+#pragma unroll
+                    for (int T = 4; T < 8; ++T) *(f32x4*)(xrow + ka.save.xhat[L] + T * kTileT) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
             LazyNorm norm;
@@ -700,7 +708,18 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
     const int e = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     if (e >= kPackedFloats || (e >= kImageFloats && e < kWideFloats)) return;      // (the bounds block's four floats)
     float v = 0.f;
-    if (e >= kNarrowBwdH8Offset) {
+    if (e >= kNarrowBwd4Offset) {
+        // transposed fp32 image at 4 register tiles (nerf_layout.h): hidden_size <= 64 training, fp32 arithmetic
+        if (pa.hidden > 64) return;
+        const int eb = e - kNarrowBwd4Offset;
+        const int stage = eb / kStageFloats;
+        const int in_stage = eb - stage * kStageFloats;
+        const int quad = in_stage / kQuadFloats;
+        const int lane = (in_stage % kQuadFloats) / 4, r = in_stage & 3;
+        const int i = lane & 15, g = lane >> 4;
+        const int tout = quad / 4, tin = quad % 4;
+        v = stage == 0 ? pa.w5(16 * tout + 4 * g + r, 16 * tin + i) : pa.wh(5 - stage, 16 * tout + 4 * g + r, 16 * tin + i);
+    } else if (e >= kNarrowBwdH8Offset) {
         // transposed split-precision image at 8 register tiles (nerf_layout.h)
         if (pa.hidden > 128) return;
         const int eb = e - kNarrowBwdH8Offset;
@@ -1059,18 +1078,20 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
         {nerf_render_fwd_kernel<false, false, false, 4>, nerf_render_fwd_kernel<false, false, true, 4>}};
     static const Kernel narrow_half[2] = {nerf_render_fwd_kernel<false, true, false, 8>, nerf_render_fwd_kernel<false, true, true, 8>};
     static const Kernel narrow_train[2] = {nerf_render_fwd_kernel<true, false, false, 8>, nerf_render_fwd_kernel<true, true, false, 8>};
-    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_half[2] = {}, done_narrow_train[2] = {};
+    static const Kernel narrow_train4 = nerf_render_fwd_kernel<true, false, false, 4>;      // hidden_size <= 64, fp32 arithmetic
+    static unsigned done[2][2][2] = {}, done_narrow[2][2] = {}, done_narrow_half[2] = {}, done_narrow_train[2] = {}, done_narrow_train4 = 0;
     // training: compositing is its own kernel, which also writes out_weights
     const int ps = !train && per_sample;
     // register tiles per sample of this launch: training 8 / 16 (train_tiles); inference 4 / 8 / 16 in fp32
     // arithmetic, 8 / 16 in split-precision arithmetic
-    int nt = train ? tt : tiles_for(shape_of(a).hidden);
+    int nt = train ? train_compute_tiles(shape_of(a).hidden, half) : tiles_for(shape_of(a).hidden);
     if (half && nt == 4) nt = 8;
     const bool is_narrow = nt < 16;
     const Kernel kernel = !is_narrow ? kernels[train][half][ps]
-                          : train ? narrow_train[half] : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
+                          : train ? (nt == 4 ? narrow_train4 : narrow_train[half]) : (half ? narrow_half[ps] : narrow[nt == 4][ps]);
     unsigned* const done_mask = !is_narrow ? &done[train][half][ps]
-                                : train ? &done_narrow_train[half] : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
+                                : train ? (nt == 4 ? &done_narrow_train4 : &done_narrow_train[half])
+                                        : (half ? &done_narrow_half[ps] : &done_narrow[nt == 4][ps]);
     // LDS: three-slot ring + small image (+ the split-precision kernel's stash); the render-only narrow kernels run a
     // two-slot ring without a stash, three workgroups per CU
     const bool three = is_narrow && !ps;

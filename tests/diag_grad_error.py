@@ -17,12 +17,19 @@ from oracle import nerf_oracle as O                         # noqa: E402
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r6_psnr")
+    hidden = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     if not os.path.exists(os.path.join(out, "scene.npz")):
         P.make_scene(out)
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")
     images, poses, focal, params0 = P.load_scene(out)
-    cfg = dict(O.default_config(), focal_length=focal)
+    cfg = dict(O.default_config(), focal_length=focal, hidden_size=hidden)
+    if hidden != 256 or scale != 1.0:
+        params0 = O.init_params(seed=0, cfg=cfg)
+        for slot in O.LINEAR_IDS:
+            params0[f"prediction_heads.{slot}.weight"] = params0[f"prediction_heads.{slot}.weight"] * scale
+    width = 128 if hidden <= 128 else 256
     rays_o, rays_d, pixels = P.host_batches(images, poses, focal)
     gen = torch.Generator().manual_seed(5)
     idx, u, noise = P.captured_step(gen, rays_o.shape[0])
@@ -64,7 +71,7 @@ def main():
     l32, g32 = oracle(torch.float32)
     runs = {"oracle fp32": g32}
     for prec in ("fp32", "f16x3"):
-        model = NeRF(focal_length=focal)
+        model = NeRF(focal_length=focal, hidden_size=hidden)
         model.load_state_dict(params0)
         model = model.to(dev)
         model.train_precision = prec
@@ -75,7 +82,7 @@ def main():
         loss.backward()
         runs["hip " + prec] = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
         import workspace_mirror as W
-        lay = W.train_layout(256, P.SAMPLES)
+        lay = W.train_layout(256, P.SAMPLES, width)
         # saved x_hat / gates against the fp64 oracle's
         with torch.no_grad():
             p64 = {k: v.double() for k, v in params0.items()}
@@ -84,15 +91,24 @@ def main():
             h64 = O.ipe_features(m64, c64, -4, cfg["encoding_size"] // 2 - 4)
             _, xh64, _ = O.mlp_stages(p64, h64)
         for L, slot in enumerate((1, 4, 7, 10, 13)):
-            xk = W.saved_xhat(model.last_workspace, L, 256, P.SAMPLES).cpu().double()
+            xk = W.saved_xhat(model.last_workspace, L, 256, P.SAMPLES, width)[..., :hidden].cpu().double()
             ga, be = params0[f"prediction_heads.{slot}.weight"].double(), params0[f"prediction_heads.{slot}.bias"].double()
             zk, z64 = xk * ga + be, xh64[L] * ga + be
             flips = (zk > 0) != (z64 > 0)
             print(f"   x_hat[{L}] hip {prec}: rms error {float((xk - xh64[L]).pow(2).mean().sqrt()):.2e}  max {float((xk - xh64[L]).abs().max()):.2e}; "
                   f"{int(flips.sum())} gates differ from the fp64 oracle's, largest |z| among them "
                   f"{float(z64[flips].abs().max()) if flips.any() else 0.0:.2e}")
+        # network outputs of the training forward (padded tile rows) and dL/d(out) against the fp64 oracle
+        with torch.no_grad():
+            raw64 = O.mlp(p64, h64)
+        got_out = W._rows(model.last_workspace, lay, lay["out"], 64, 256, P.SAMPLES)     # stored as tiles: see below
+        tiles = model.last_workspace[lay["out"]:lay["out"] + lay["mp"] * 64].view(-1, 4, 4, 16, 4)     # [tile][T][g][s][r]
+        rows = tiles.permute(0, 3, 1, 2, 4).reshape(lay["mp"], 64).view(lay["mp"] // (lay["chunks"] * 16), lay["chunks"] * 16, 64)
+        out_k = rows[:256, :P.SAMPLES - 1, :raw64.shape[-1]].cpu().double()
+        print(f"   out hip {prec}: max|out| {float(raw64.abs().max()):.2e}  max|e| {float((out_k - raw64).abs().max()):.2e}  rms e "
+              f"{float((out_k - raw64).pow(2).mean().sqrt()):.2e}")
         for L in range(5):
-            got = W._rows(model.last_workspace, lay, lay["dy"][L], 256, 256, P.SAMPLES).cpu().double()
+            got = W._rows(model.last_workspace, lay, lay["dy"][L], width, 256, P.SAMPLES)[..., :hidden].cpu().double()
             e, e32 = got - dy64[L], dy32[L].double() - dy64[L]
             per_sample = e.mean(-1)                       # an additive per-sample offset shows here
             print(f"   dY[{L}] hip {prec}: max|dy| {float(dy64[L].abs().max()):.2e}  max|e| {float(e.abs().max()):.2e}  rms e "

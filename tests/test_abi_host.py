@@ -35,8 +35,8 @@ def test_library_exports_every_declared_symbol(handle):
     assert handle.nerf_hip_version() == _lib.ABI_VERSION == 8
     # packed image = {74 forward stages + 3,904 small floats + 68 transposed stages of 16 KiB} x {fp32, f16 pairs}
     # + four bound constants + the narrow images: fp32 forward (21 stages at 8 register tiles, 7 at 4), transposed
-    # fp32 (18 at 8), f16-pair forward (21) and transposed (18) at 8
-    assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4 + 68 * 16384) + 16 + (21 + 7 + 18 + 21 + 18) * 16384
+    # fp32 (18 at 8), f16-pair forward (21) and transposed (18) at 8, transposed fp32 at 4 (5)
+    assert handle.nerf_hip_packed_bytes() == 2 * (74 * 16384 + 3904 * 4 + 68 * 16384) + 16 + (21 + 7 + 18 + 21 + 18 + 5) * 16384
     ge = handle.nerf_hip_grad_elements
     assert ge(256, 96, 54) == 304438                          # the reference's defaults: hidden 256, 3 x 32 inputs, 1 + 3 + 50 outputs
     assert ge(256, 96, 4) == 304438 - 50 * 257 and ge(256, 96, 64) == 304438 + 10 * 257
