@@ -253,7 +253,14 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
         _, dens, col, _ = model(o, d, t.contiguous())
     ok = stable_rays(g["last_density"])
     assert (rgb[:, 0].cpu() - g["rgb"])[ok].abs().max() <= 1e-5                 # (BASELINE bar: 1e-4)
-    assert (seg[:, 0].cpu() - g["seg_out"])[ok].abs().max() <= 1e-4
+    # log-probabilities: 1e-4 + what fp32 does to the reference's own formula on these rays (a ray of little total
+    # weight takes its weights from 1 - exp(-x) at small x: the reference against the fp64 oracle measures it; x 8 as
+    # in test_forward_vs_oracle)
+    with torch.no_grad():
+        cfg64 = dict(O.default_config(), **kw)
+        _, seg64 = O.render_rays({k: v.double() for k, v in params.items()}, cfg64, g["rays_o"].double(), g["rays_d"].double(), 48)
+    seg_floor = float((g["seg_out"].double() - seg64)[ok].abs().max())
+    assert (seg[:, 0].cpu() - g["seg_out"])[ok].abs().max() <= 1e-4 + 8 * seg_floor, seg_floor
     assert (dens.cpu() - g["density"]).abs().max() <= 2e-5 * max(1.0, float(g["density"].abs().max()))
     assert (col.cpu() - g["color"]).abs().max() <= 2e-5 * max(1.0, float(g["color"].abs().max()))
     model.keep_workspace = True
@@ -283,7 +290,7 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
     for k, p in model.named_parameters():
         assert rel_err(plain[k], g["grad." + k]) <= 1e-5, k          # the oracle IS the reference here
         e = rel_err(p.grad.cpu(), g["grad." + k])
-        assert e <= (1e-5 if flips == 0 else 5e-6 + 8 * floor + 2e-4 * flips), (k, e, floor, flips)
+        assert e <= 5e-6 + 8 * floor + 2e-4 * flips, (k, e, floor, flips)
 
 
 def test_shapes_the_kernels_do_not_take_are_refused():
