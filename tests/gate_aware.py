@@ -23,6 +23,22 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
 
 
+def rays_with_weight(params, cfg, o, d, num_samples, u, noise, noise_std, least=0.02):
+    """Mask [n] of the rays whose total compositing weight (fp64 oracle) is at least ``least``.  The segmentation
+    output is log(w + 1e-10) + ..., whose gradient carries 1 / w: on a ray of total weight 5e-3 whose one contributing
+    sample has a density that all but cancels its noise draw (sigma = 1.2 - 1.195), the 1e-5 with which ANY fp32
+    forward rounds that density is 4e-4 of sigma, of w and of every gradient the ray's segmentation term feeds — the
+    fp32 oracle itself moves by that much from one summation order to the next (tests/diag_seg_grad.py; profiles/
+    r06_d_seg_gradient_diag.log).  Gradient tests put their segmentation loss on the rays above the threshold."""
+    from oracle import nerf_oracle as O
+    with torch.no_grad():
+        p64 = {k: v.double() for k, v in params.items()}
+        st = O.render_rays(p64, cfg, o.double(), d.double(), num_samples, u=None if u is None else u.double(),
+                           noise=None if noise is None else noise.double(), density_noise_std=noise_std,
+                           return_stages=True)[2]
+    return st["weights"].sum(dim=(1, 2)) >= least
+
+
 def caster(p):
     """t -> t in the dtype of the parameter dict ``p`` (the oracle runs in fp32 and in fp64)."""
     dtype = next(v for v in p.values()).dtype

@@ -118,6 +118,8 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
     noise = torch.randn(n_rays, num_samples - 1, 1)
     w_rgb = torch.randn(n_rays, 3)
     w_seg = torch.randn(n_rays, 50) * 0.05
+    import gate_aware
+    w_seg = w_seg * gate_aware.rays_with_weight(params, CFG, o, d, num_samples, u, noise, 0.5)[:, None]   # (1 / w: see there)
 
     ref = {k: v.clone().requires_grad_(k.startswith("prediction")) for k, v in params.items()}
     rgb_r, seg_r = O.render_rays(ref, CFG, o, d, num_samples, u=u, noise=noise, density_noise_std=0.5)
@@ -131,8 +133,6 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
     loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + ((seg[:, 0] * w_seg.to(dev)).sum() if with_seg else 0.0)
     loss.backward()
     assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-4 * max(1.0, abs(float(loss_r.detach())))
-
-    import gate_aware
 
     def gated_loss(p, gates, record):
         c = gate_aware.caster(p)

@@ -127,6 +127,8 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
     noise = torch.randn(n, S - 1, 1, generator=g)
     w_rgb = torch.randn(n, colors, generator=g)
     w_seg = torch.randn(n, classes, generator=g) * 0.05
+    import gate_aware
+    w_seg = w_seg * gate_aware.rays_with_weight(params, cfg, o, d, S, u, noise, 0.5)[:, None]     # (1 / w: see there)
 
     def loss_of(p, cast):
         rgb, seg = O.render_rays(p, cfg, cast(o), cast(d), S, u=cast(u), noise=cast(noise), density_noise_std=0.5)
@@ -146,7 +148,6 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
                                  u=u.to(dev), noise=noise.to(dev))
     loss = (rgb[:, 0] * w_rgb.to(dev)).sum() + (seg[:, 0] * w_seg.to(dev)).sum()
     loss.backward()
-    import gate_aware
 
     def gated_loss(p, gates, record):
         c = gate_aware.caster(p)
