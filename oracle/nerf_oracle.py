@@ -232,11 +232,12 @@ def field(params, cfg, rays_o, rays_d, t, gates=None, record=None):
 # a11-a13: compositing
 # --------------------------------------------------------------------------
 
-def composite_weights(points, density):
-    """alpha_compositing_coefficients (model.py:438-469)."""
+def composite_weights(points, density, gate=None):
+    """alpha_compositing_coefficients (model.py:438-469).  ``gate`` (test aid, see ``mlp``): a boolean tensor to use
+    INSTEAD of the density's own ReLU gate (density * gate in place of relu(density))."""
     gaps = points[..., 1:, :] - points[..., :-1, :]
     dists = F.pad(torch.linalg.norm(gaps, dim=-1, keepdim=True), (0, 0, 0, 1), value=1e10)
-    trans = torch.exp(-F.relu(density) * dists)
+    trans = torch.exp(-(F.relu(density) if gate is None else density * gate.to(density.dtype)) * dists)
     return (1.0 - trans) * F.pad(torch.cumprod(trans[..., :-1, :] + 1e-10, dim=-2),
                                  (0, 0, 1, 0), value=1.0)
 
@@ -252,7 +253,10 @@ def render_rays(params, cfg, rays_o, rays_d, num_samples, u=None, noise=None,
     means, covs, h, density, color, seg = field(params, cfg, rays_o, rays_d, t, gates=gates, record=record)
     if noise is not None:
         density = density + noise * density_noise_std                           # :652-654
-    weights = composite_weights(means, density)                                 # :658
+    # (test aid: a sixth entry of ``gates`` / ``record`` is the ReLU gate of the (noisy) density in the compositing)
+    if record is not None:
+        record.append((density > 0).detach())
+    weights = composite_weights(means, density, gates[5] if gates is not None and len(gates) > 5 else None)   # :658
     rgb = (weights * torch.sigmoid(color)).sum(dim=-2)                          # :660
     seg_out = (torch.log(weights + 1e-10)
                + torch.log_softmax(seg, dim=-1)).logsumexp(dim=-2)              # :661-663

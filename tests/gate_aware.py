@@ -5,7 +5,8 @@ falls on either side depending on the summation order of the LayerNorm that feed
 tensor by 1e-4 of its largest element (round 5: the first G11 fixture).  So the comparison is split in two:
 
 * the ARITHMETIC: the oracle differentiates with the gates the KERNEL ran with (read from the workspace its training
-  forward saved: fma(x_hat, gamma, beta) > 0, tests/workspace_mirror.py: saved_gates), i.e. both sides differentiate
+  forward saved: fma(x_hat, gamma, beta) > 0 of the five hidden layers and density + noise > 0 of the compositing,
+  tests/workspace_mirror.py: saved_gates / saved_density_gate), i.e. both sides differentiate
   the same piecewise-linear function — every gradient tensor must agree to ``grad_bound`` of its largest element;
 * the GATES: the kernel's gates against the oracle's own — they may differ only in a bounded share of elements
   (``flip_bound``), the ones within rounding of zero.
@@ -47,7 +48,8 @@ def caster(p):
 
 def kernel_gates(model, params, n_rays, num_samples):
     """Gates of the training forward ``model`` just ran (``model.keep_workspace`` must have been set before it)."""
-    return W.saved_gates(model.last_workspace, params, n_rays, num_samples)
+    return W.saved_gates(model.last_workspace, params, n_rays, num_samples) + \
+        [W.saved_density_gate(model.last_workspace, params, n_rays, num_samples)]
 
 
 def oracle_gradients(params, loss_fn, gates=None, record=None, dtype=torch.float32):
@@ -69,7 +71,7 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
     _, plain = oracle_gradients(params, loss_fn, record=own)
     _, ref32 = oracle_gradients(params, loss_fn, gates=gates)
     _, ref64 = oracle_gradients(params, loss_fn, gates=gates, dtype=torch.float64)
-    assert len(own) == len(gates) == 5 and all(a.shape == b.shape for a, b in zip(own, gates))
+    assert len(own) == len(gates) == 6 and all(a.shape == b.shape for a, b in zip(own, gates))      # five LayerNorm-ReLU gates + the density's
     flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
     total = sum(a.numel() for a in gates)
     assert flips <= max(flip_bound * total, 2), (flips, total)

@@ -102,6 +102,15 @@ def saved_rstd(workspace, layer, n_rays, num_samples, width=HIDDEN):
     return _rows(workspace, lay, lay["rstd"][layer], 1, n_rays, num_samples)[..., 0]
 
 
+def saved_density_gate(workspace, params, n_rays, num_samples):
+    """The ReLU gate of the (noisy) density the compositing ran with and its backward differentiates through:
+    slot 3 of the compositing state [sp][4] = (alpha, T_exclusive, dist, density + noise) > 0; [n_rays, S-1, 1]."""
+    hidden = params["prediction_heads.1.weight"].shape[0]
+    lay = train_layout(n_rays, num_samples, train_width(hidden))
+    comp = _rows(workspace, lay, lay["comp"], 4, n_rays, num_samples)
+    return (comp[..., 3:4] > 0).cpu()
+
+
 def saved_gates(workspace, params, n_rays, num_samples):
     """The five ReLU gates [n_rays, S-1, hidden_size] the training forward ran with AND its backward differentiates
     through: both evaluate fma(x_hat, gamma, beta) > 0 on the saved x_hat (nerf_fused.h: normalize_tile,
