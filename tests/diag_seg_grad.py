@@ -53,6 +53,20 @@ def main():
         print(f"[{name}] worst tensor: kernel vs fp64 {max(rel(gk[k], g64[k]) for k in g64):.2e}, oracle fp32 vs fp64 "
               f"{max(rel(g32[k], g64[k]) for k in g64):.2e}; last bias: kernel {rel(gk['prediction_heads.15.bias'], g64['prediction_heads.15.bias']):.2e} "
               f"oracle fp32 {rel(g32['prediction_heads.15.bias'], g64['prediction_heads.15.bias']):.2e}")
+    # the last bias gradient element by element (= column sums of dL/d out), and against the sum of the dL/d(out) rows the
+    # compositing backward left in the workspace (what the weight-gradient kernel summed)
+    import workspace_mirror as W
+    model.keep_workspace = True
+    sk, gk = kernel(1.0, 1.0)
+    _, _, g64 = oracle(torch.float64, 1.0, 1.0)
+    b_k, b_64 = gk["prediction_heads.15.bias"], g64["prediction_heads.15.bias"]
+    lay = W.train_layout(n, S, W.train_width(hidden))
+    rows = model.last_workspace[lay["dy5"]:lay["dy5"] + lay["mp"] * 64].view(lay["mp"], 64).cpu().double()
+    col = rows.sum(0)[:54]
+    scale = float(b_64.abs().max())
+    print("last bias, (kernel - fp64) / max, per row:", " ".join(f"{float(x):+.1e}" for x in (b_k - b_64) / scale))
+    print("last bias, (sum of workspace dOut rows - fp64) / max:", " ".join(f"{float(x):+.1e}" for x in (col - b_64) / scale))
+    print("last bias fp64 / max:", " ".join(f"{float(x):+.2f}" for x in b_64 / scale))
     ds_k, ds_32 = (sk - s64), (s32 - s64)
     heavy = s64.exp() > 1e-3
     print(f"forward seg (log-probabilities): kernel - fp64 max {float(ds_k.abs().max()):.2e} (heavy classes {float(ds_k[heavy].abs().max()):.2e}), "
