@@ -63,14 +63,25 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
     """``loss_fn(p, gates, record)``: the oracle's loss on parameter dict ``p`` (in ITS dtype: the function casts its
     other inputs to ``next(iter(p.values())).dtype``), passing ``gates`` / ``record`` through to
     oracle.nerf_oracle.mlp.  ``model`` holds the kernel's gradients (p.grad) of the same loss.  Every tensor must lie
-    within ``grad_bound`` + 4 x (the fp32 oracle's own distance from the fp64 oracle, both on the kernel's gates) of
-    the fp64 or the fp32 oracle on the kernel's gates, relative to its largest element.
+    within ``grad_bound`` + 4 x (the fp32 oracle's own distance from the fp64 oracle, both on the kernel's gates: the
+    largest of four fp32 evaluations) of the fp64 or the fp32 oracle on the kernel's gates, relative to its largest
+    element.
     Returns (flips, total, worst error, the fp32 oracle's gradients on its OWN gates)."""
     gates = kernel_gates(model, params, n_rays, num_samples)
     own = []
     _, plain = oracle_gradients(params, loss_fn, record=own)
     _, ref32 = oracle_gradients(params, loss_fn, gates=gates)
     _, ref64 = oracle_gradients(params, loss_fn, gates=gates, dtype=torch.float64)
+    # the floor: what fp32 ROUNDING does to these gradients.  One fp32 evaluation is one draw from a heavy-tailed
+    # distribution when a ray of little weight amplifies the forward's rounding by 1 / w (rays_with_weight above), so
+    # three more draws are taken — the fp32 oracle on parameters moved by one ulp at random (a change of 6e-8 in the
+    # true gradient) — and the largest distance from the fp64 oracle counts
+    instances = [ref32]
+    gen = torch.Generator().manual_seed(12345)
+    for _ in range(3):
+        moved = {k: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).to(v.dtype) * 2 - 1) * 2.0 ** -23)
+                     if k.startswith("prediction") else v) for k, v in params.items()}
+        instances.append(oracle_gradients(moved, loss_fn, gates=gates)[1])
     assert len(own) == len(gates) == 6 and all(a.shape == b.shape for a, b in zip(own, gates))      # five LayerNorm-ReLU gates + the density's
     flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
     total = sum(a.numel() for a in gates)
@@ -78,7 +89,7 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
     worst, table, bad = 0.0, [], []
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == ref64[k].shape, k
-        floor = rel_err(ref32[k], ref64[k])
+        floor = max(rel_err(inst[k], ref64[k]) for inst in instances)
         # (against the nearer of the two oracles: what fp32 does to the encoding's large arguments moves layer 0's
         #  gradient by 4e-5 for kernel and fp32 oracle alike, while an accumulation over thousands of samples lands
         #  nearer the fp64 one)
@@ -90,6 +101,6 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
             bad.append(k)
     assert not bad, f"[{tag}] {bad}\n" + "\n".join(table)
     print(f"[{tag}] worst relative gradient error on the kernel's gates {worst:.2e} (fp32 oracle, same gates: "
-          f"{max(rel_err(ref32[k], ref64[k]) for k in ref64):.2e}); {flips} of {total} gates differ from the oracle's own "
+          f"{max(rel_err(inst[k], ref64[k]) for inst in instances for k in ref64):.2e}); {flips} of {total} gates differ from the oracle's own "
           f"(against the oracle on ITS gates: {max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
     return flips, total, worst, plain
