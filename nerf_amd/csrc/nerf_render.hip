@@ -78,12 +78,11 @@ __device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x
                     be = norm.bet[t + 1];
                 }
             } else if (t + 1 < KT) {
-                // training: the x_hat store of this stage (group 1, in front of this hand-over) and the one of the
-                // previous stage are YOUNGER than the DMA of the stage being opened (issued two hand-overs ago): the
-                // counted wait leaves them in flight instead of exposing an HBM write acknowledgement per stage
-                // (nerf_device.h: open_stage<kYounger>; the split-precision layer does the same)
-                if (kTrain && kNormIn) st = t >= 1 ? pipe.template open_stage<2>() : pipe.template open_stage<1>();
-                else st = pipe.open_stage();
+                // (training: the wait also covers this stage's and the previous stage's x_hat store.  Counting them out —
+                //  open_stage<2>, as the split-precision layer does — was built and measured in round 6: forward / data
+                //  gradient time ratio 0.971 against 0.965 - 0.985 before, i.e. nothing: an fp32 stage is 0.85 us of
+                //  MFMAs, long enough for a store's acknowledgement)
+                st = pipe.open_stage();
                 a[nxt][0] = st[0];
                 a[nxt][1] = st[64];
                 pipe.prefetch_next();
