@@ -102,7 +102,7 @@ def oracle_run(out, tag, threads, steps, every, seed, own_draws):
             print(f"[{tag}] step {step}: loss {losses[-1]:.6f}, held-out PSNR {psnrs[step]:.4f} dB, "
                   f"{time.perf_counter() - t0:.0f} s", flush=True)
     result = {"tag": tag, "kind": "oracle (CPU port of the reference's ops, torch Adam)", "threads": threads,
-              "seed": seed, "draws": "own torch generator" if own_draws else "captured stream", "steps": steps,
+              "seed": seed, "lr": LR, "draws": "own torch generator" if own_draws else "captured stream", "steps": steps,
               "seconds": time.perf_counter() - t0, "loss": losses, "psnr": psnrs}
     with open(os.path.join(out, f"traj_{tag}.json"), "w") as f:
         json.dump(result, f)
@@ -146,7 +146,7 @@ def hip_run(out, tag, steps, every, seed, train_precision, graph, rng):
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     result = {"tag": tag, "kind": "HIP Trainer (nerf_amd.trainer.Trainer)", "train_precision": train_precision,
-              "graph_replay": bool(graph), "replayed": run._graph is not None, "seed": seed,
+              "graph_replay": bool(graph), "replayed": run._graph is not None, "seed": seed, "lr": LR,
               "draws": "captured stream" if rng == "captured" else "in-kernel Philox", "steps": steps,
               "seconds": seconds, "loss": [float(x) for x in torch.stack(losses).cpu()],
               "psnr": psnrs}
@@ -169,7 +169,7 @@ def make_scene(out):
 
 def spawn_oracle(out, tag, threads, steps, every, seed, own):
     cmd = [sys.executable, os.path.abspath(__file__), "oracle", "--out", out, "--tag", tag, "--threads", str(threads),
-           "--steps", str(steps), "--every", str(every), "--seed", str(seed)] + (["--own-draws"] if own else [])
+           "--steps", str(steps), "--every", str(every), "--seed", str(seed), "--lr", str(LR)] + (["--own-draws"] if own else [])
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="",
                HIP_VISIBLE_DEVICES="")
     log = open(os.path.join(out, f"traj_{tag}.log"), "w")
@@ -187,7 +187,7 @@ def merge(out, path):
             runs[r["tag"]] = r
     record = {"what": "held-out PSNR of the training loop of train_conditional_nerf.py:115-153 on a synthetic stand-in "
                       f"scene ({VIEWS} views {SIZE}x{SIZE}, last held out), {BATCH}-ray batches, {SAMPLES} samples/ray, "
-                      f"Adam lr {LR}, density noise {NOISE_STD}; oracle = CPU port of the reference (the reference itself "
+                      f"Adam lr {next(iter(runs.values())).get('lr', LR) if runs else LR}, density noise {NOISE_STD}; oracle = CPU port of the reference (the reference itself "
                       "does not travel to the GPU box)",
               "runs": {t: {k: v for k, v in r.items() if k != "loss"} for t, r in runs.items()}}
     base = runs.get("cpu_mt")
@@ -261,8 +261,11 @@ def main():
     ap.add_argument("--own-draws", action="store_true")
     ap.add_argument("--seeds", type=int, default=3, help="part rng: seeds per side")
     ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=LR, help="Adam learning rate (the reference's script: 1e-4)")
+    ap.add_argument("--oracle-threads", default="1,2,4,8", help="part captured: thread counts of the oracle runs (the last one is the base, cpu_mt)")
     ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r06_psnr_parity.json"))
     args = ap.parse_args()
+    globals()["LR"] = args.lr
     if args.cmd == "scene":
         return make_scene(args.out)
     if args.cmd == "oracle":
@@ -272,8 +275,9 @@ def main():
     # run: the oracle trajectories first, as children, before this process touches the GPU
     if args.part == "captured":
         # four summation orders of the SAME algorithm on the SAME draws (1 + 2 + 4 + 8 = 15 of the box's 16 CPUs)
-        kids = [spawn_oracle(args.out, f"cpu_{t}t" if t < 8 else "cpu_mt", t, args.steps, args.every, args.seed, False)
-                for t in (1, 2, 4, 8)]
+        threads = [int(t) for t in args.oracle_threads.split(",")]
+        kids = [spawn_oracle(args.out, f"cpu_{t}t" if t != threads[-1] else "cpu_mt", t, args.steps, args.every, args.seed, False)
+                for t in threads]
         for tag, prec, graph in (("hip_fp32", "fp32", False), ("hip_f16x3", "f16x3", False),
                                  ("hip_f16x3_graph", "f16x3", True), ("hip_fp32_graph", "fp32", True)):
             hip_run(args.out, tag, args.steps, args.every, args.seed, prec, graph, "captured")

@@ -165,6 +165,55 @@ def test_gradients_vs_oracle_autograd(shape, train_precision):
         assert p.grad is not None and p.grad.shape == ref[k].shape, k
 
 
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("shape", [(9, 128, 32, 7), (50, 256, 32, 1), (0, 64, 16, 4), (51, 256, 32, 12)])
+def test_differentiable_forward_with_other_color_counts(shape, train_precision):
+    """NeRF.forward under autograd (nerf/model.py:553-594) at color_outputs 7 / 1 / 4 / 12: the per-sample outputs come
+    out of the training forward's padded tile through the slot -> row map and dL/d(raw) goes back in through it
+    (nerf_layout.h: row_of_slot; nerf_field_outputs_kernel / nerf_field_scatter_kernel), no compositing on either side.
+    Values against the oracle's field(), all 22 gradients gate-aware against its autograd."""
+    import gate_aware
+    dev = torch.device("cuda:0")
+    classes, colors = shape[0], colors_of(shape)
+    cfg, params, model = setup(shape, seed=70 + colors)
+    model.train_precision = train_precision
+    n, S = 37, 21
+    g = torch.Generator().manual_seed(9)
+    o, d = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    t = torch.sort(torch.rand(n, S, generator=g) * 30 + 0.1, dim=-1).values
+    w_d = torch.randn(n, S - 1, 1, generator=g)
+    w_c = torch.randn(n, S - 1, colors, generator=g)
+    w_s = torch.randn(n, S - 1, classes, generator=g) * 0.1
+
+    def field_loss(p, gates, record):
+        c = gate_aware.caster(p)
+        _, _, _, dens, col, seg = O.field(p, cfg, c(o), c(d), c(t), gates=gates, record=record)
+        if record is not None:
+            record.append(torch.ones(n, S - 1, 1, dtype=torch.bool))       # (no compositing: no density gate to compare)
+        return (dens * c(w_d)).sum() + (col * c(w_c)).sum() + (seg * c(w_s)).sum()
+
+    with torch.no_grad():
+        _, _, _, dens_r, col_r, seg_r = O.field(params, cfg, o, d, t)
+    model.keep_workspace = True
+    mean, dens, col, seg = model(o.to(dev), d.to(dev), t.to(dev))
+    assert dens.shape == (n, S - 1, 1) and col.shape == (n, S - 1, colors) and seg.shape == (n, S - 1, classes)
+    for got, want in ((dens, dens_r), (col, col_r), (seg, seg_r)):
+        if want.numel():
+            assert (got.detach().cpu() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
+    ((dens * w_d.to(dev)).sum() + (col * w_c.to(dev)).sum() + (seg * w_s.to(dev)).sum()).backward()
+    gates = gate_aware.W.saved_gates(model.last_workspace, params, n, S) + [torch.ones(n, S - 1, 1, dtype=torch.bool)]
+    own = []
+    _, plain = gate_aware.oracle_gradients(params, field_loss, record=own)
+    _, ref64 = gate_aware.oracle_gradients(params, field_loss, gates=gates[:5], dtype=torch.float64)
+    _, ref32 = gate_aware.oracle_gradients(params, field_loss, gates=gates[:5])
+    flips = sum(int((a != b).sum()) for a, b in zip(own[:5], gates[:5]))
+    assert flips <= max(1e-5 * sum(a.numel() for a in gates[:5]), 2), flips
+    for k, p in model.named_parameters():
+        floor = rel_err(ref32[k], ref64[k])
+        e = min(rel_err(p.grad.cpu(), ref64[k]), rel_err(p.grad.cpu(), ref32[k]))
+        assert e <= 5e-6 + 4 * floor, (k, e, floor)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("strength", [1.0, 20.0])
 @pytest.mark.parametrize("shape", [(50, 256, 32), (50, 128, 32), (7, 64, 16), (3, 40, 10)])
