@@ -237,8 +237,15 @@ def kernel_split(dev, fn, steps=20):
 
 
 def train_tiles_of(hidden):
-    """Register tiles per sample the TRAINING kernels of a network run at (nerf_amd/csrc/nerf_device.h: train_tiles)."""
+    """Register tiles per sample the TRAINING kernels of a network run at (nerf_amd/csrc/nerf_device.h: train_tiles):
+    the saved rows and the weight gradient."""
     return 16 if hidden > 128 else 8
+
+
+def train_compute_tiles_of(hidden, train_precision):
+    """... and the tiles its training forward and data gradient COMPUTE at (nerf_device.h: train_compute_tiles): 4 for
+    hidden_size <= 64 in fp32 arithmetic."""
+    return 4 if hidden <= 64 and train_precision == "fp32" else train_tiles_of(hidden)
 
 
 def train_step_timing(dev, rays=4096, samples=64, steps=SHORT_STEPS, warmup=5, train_precision="fp32", hidden=256, enc=32):
@@ -276,8 +283,9 @@ def train_step_timing(dev, rays=4096, samples=64, steps=SHORT_STEPS, warmup=5, t
                             f"encoding_size={enc} ({flop} FLOP per sample)",
                 **timing, "ray_samples_per_s": rays * samples / dt, "tflops_fwd_dgrad_wgrad": tflops,
                 "arithmetic": ("fp32 MFMA forward and data gradient, bf16-triple weight gradient" if train_precision == "fp32"
-                               else "f16 pairs in all three kernels") + f", at {train_tiles_of(hidden)} register tiles per sample "
-                              "(the network's own cost)"}
+                               else "f16 pairs in all three kernels") +
+                              f", training forward and data gradient at {train_compute_tiles_of(hidden, train_precision)} register "
+                              f"tiles per sample, saved rows and weight gradient at {train_tiles_of(hidden)} (the network's own cost)"}
     return {"workload": f"{rays} rays x {samples} samples, forward + backward + Adam",
             **timing, "ray_samples_per_s": rays * samples / dt,
             "tflops_fwd_dgrad_wgrad": tflops,
@@ -958,7 +966,7 @@ def main():
             line["train_step_f16x3"] = train_step_timing(dev, train_precision="f16x3")
             line["train_step_hidden128"] = train_step_timing(dev, hidden=128)
             line["train_step_hidden128_f16x3"] = train_step_timing(dev, hidden=128, train_precision="f16x3")
-            # hidden_size <= 64 trains at 8 register tiles too (no 4-tile weight gradient): 128's cost
+            # hidden_size <= 64: forward and data gradient at 4 register tiles, the weight gradient at 8
             line["train_step_hidden64_enc16"] = train_step_timing(dev, hidden=64, enc=16)
             line["train_step_512_graph"] = small_batch_step_timing(dev)
             line["legacy_network"] = legacy_workload_timing(dev)
