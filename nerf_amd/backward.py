@@ -105,6 +105,8 @@ class FieldFunction(torch.autograd.Function):
         _, _, mean, raw, _ = model._launch(n_rays, num_samples, device, rays_o=rays_o, rays_d=rays_d,
                                            t_values=samples, per_sample=True, train_workspace=workspace,
                                            composite=False)
+        if getattr(model, "keep_workspace", False):      # debugging / stage-parity tests only
+            model.last_workspace = workspace
         ctx.model = model
         ctx.call = (rays_o, rays_d, samples)
         ctx.workspace = workspace

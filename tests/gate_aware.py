@@ -59,15 +59,17 @@ def oracle_gradients(params, loss_fn, gates=None, record=None, dtype=torch.float
     return float(loss.detach()), {k: v.grad.float() for k, v in p.items() if v.grad is not None}
 
 
-def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, flip_bound=FLIP_BOUND, tag=""):
+def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, flip_bound=FLIP_BOUND, tag="", gates=None):
     """``loss_fn(p, gates, record)``: the oracle's loss on parameter dict ``p`` (in ITS dtype: the function casts its
     other inputs to ``next(iter(p.values())).dtype``), passing ``gates`` / ``record`` through to
     oracle.nerf_oracle.mlp.  ``model`` holds the kernel's gradients (p.grad) of the same loss.  Every tensor must lie
     within ``grad_bound`` + 4 x (the fp32 oracle's own distance from the fp64 oracle, both on the kernel's gates: the
     largest of four fp32 evaluations) of the fp64 or the fp32 oracle on the kernel's gates, relative to its largest
-    element.
+    element.  ``gates``: the kernel's six gates when the caller read them itself (a loss without compositing has no
+    density gate in the workspace).
     Returns (flips, total, worst error, the fp32 oracle's gradients on its OWN gates)."""
-    gates = kernel_gates(model, params, n_rays, num_samples)
+    if gates is None:
+        gates = kernel_gates(model, params, n_rays, num_samples)
     own = []
     _, plain = oracle_gradients(params, loss_fn, record=own)
     _, ref32 = oracle_gradients(params, loss_fn, gates=gates)
