@@ -47,8 +47,9 @@ __host__ __device__ inline int small_lds_index(int i) {
     return L * kSmallPerLayerLds + which * kSmallArrayLds + (q / 64) * kSmallGStride + (q % 64);
 }
 // global -> LDS copy by the whole workgroup (256 threads)
+template <int kThreads = 256>
 __device__ __forceinline__ void stage_small_image(const float* small_g, float* small_l) {
-    for (int i = threadIdx.x; i < kSmallFloats; i += 256) small_l[small_lds_index(i)] = small_g[i];
+    for (int i = threadIdx.x; i < kSmallFloats; i += kThreads) small_l[small_lds_index(i)] = small_g[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,6 +163,7 @@ constexpr NormDivisor kFullWidth = {1.0f / 256.0f, 256};
 template <int kStagesInImage, int kDepth = 3>
 struct WeightPipe {
     static constexpr int kRingDepth = kDepth;
+    static constexpr int kPrioMfma = NERF_PRIO_MFMA, kPrioValu = NERF_PRIO_VALU;
     const char* blob;           // packed image, stage 0
     char* ring;                 // LDS ring base
     int issue_stage;            // next stage of the image to issue (cyclic)
@@ -252,6 +254,62 @@ struct WeightPipe {
         asm volatile("" ::: "memory");
         issue();
     }
+};
+
+// The same interface over a weight image that is RESIDENT in LDS: a network of hidden_size <= 64 is 7 stages = 112 KiB
+// (nerf_layout.h: Narrow<4>), so one workgroup of kWaves waves per CU loads it ONCE and every stage "opens" as a pointer
+// into it — no DMA in the loop, no vmcnt wait, no barrier: the waves of the workgroup never meet again, each walks its
+// own rays.  Worth 3 % on the hidden-64 frame (47.4 -> 45.9 ms), not more: that kernel's time is its MFMA cycles PLUS
+// its VALU cycles (the exact-fp32 MFMA and the VALU exclude each other on this chip — scripts/probes/
+// mfma32_valu_coexec.hip, NOTES.md section R6d), which no arrangement of waves changes.
+template <int kStagesInImage, int kWaves>
+struct ResidentPipe {
+    static constexpr int kRingDepth = 0;          // (no ring: nothing for isa_scan rule R6 to count)
+    // (measured: MFMA 0 / VALU 2 as in the ring kernels 45.8 ms on the hidden-64 frame, every other order 48.1)
+    static constexpr int kPrioMfma = NERF_PRIO_MFMA, kPrioValu = NERF_PRIO_VALU;
+    char* image;                // LDS copy of the packed image
+    int read_stage;             // stage the next open_stage() hands out (cyclic)
+    int lane;
+
+    // Called by every wave of the workgroup; ends in a barrier.  4 KiB chunk c of the image (4 DMA pieces, as
+    // WeightPipe::issue) by wave c % kWaves.
+    __device__ __forceinline__ void init(const void* packed_image, char* lds, int w, int l) {
+        image = lds;
+        read_stage = 0;
+        lane = l;
+        constexpr int kChunks = kStagesInImage * kStageBytes / 4096;
+#pragma unroll 1
+        for (int c = w; c < kChunks; c += kWaves) {
+            const uint32_t dst = (uint32_t)(uintptr_t)(lds + c * 4096);
+            const uint64_t base_u = (uint64_t)(uintptr_t)((const char*)packed_image + (size_t)c * 4096);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+            const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+            uint32_t m0_saved;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 2\n\t"
+                "global_load_lds_dwordx4 %1, %3\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(m0_saved)
+                : "v"(l * 16), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(sbase)
+                : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void issue() {}
+    template <int kYounger = 0>
+    __device__ __forceinline__ const f32x4* open_stage() {
+        const f32x4* p = (const f32x4*)(image + read_stage * kStageBytes) + lane;
+        read_stage = (read_stage + 1 == kStagesInImage) ? 0 : read_stage + 1;
+        return p;
+    }
+    __device__ __forceinline__ void prefetch_next() {}
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -614,6 +672,42 @@ __device__ __forceinline__ void scatter_level4(const float (&lo)[8], const float
           "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
 }
 #undef NERF_DPP8
+// The same level for FOUR values (the second half of a 16-value butterfly): out[i] = lo[i] + (lo[i] of the lane 4
+// above) in banks 0, 2 and hi[i] + (hi[i] of the lane 4 below) in banks 1, 3.
+__device__ __forceinline__ void scatter_level4(const float (&lo)[4], const float (&hi)[4], float (&out)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+}
+// Sum over the 16 lanes of a row of SIXTEEN per-lane values, scattered: lane j of every row gets the row's sum of
+// v[j] — 16 + 8 + 8 DPP adds and 4 selects, against 64 DPP adds and 32 selects for sixteen row_sum()s of which one
+// lane each keeps the result.  (Inputs: results of compiler-visible VALU instructions, isa_scan rule R1.)
+__device__ __forceinline__ float row_scatter_sum16(const float (&v)[16], int lane) {
+    float lo[8], hi[8], h8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = v[i], hi[i] = v[8 + i];
+    scatter_level8(lo, hi, h8);          // lanes 0-7: v[i] of lanes j, j + 8; lanes 8-15: v[8 + i]
+    const float a4[4] = {h8[0], h8[1], h8[2], h8[3]}, b4[4] = {h8[4], h8[5], h8[6], h8[7]};
+    float q[4];
+    scatter_level4(a4, b4, q);           // lane quads 0, 2: v[.. + i], quads 1, 3: v[.. + 4 + i]
+    float kept = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float x = q[t];
+        x += dpp<kQuadXor1>(0.f, x);
+        x += dpp<kQuadXor2>(0.f, x);
+        kept = (lane & 3) == t ? x : kept;
+    }
+    return kept;
+}
 // x[i]: the level-4 results of tile group t (tiles t, t + 4, t + 8, t + 12) -> all-reduce inside the quad; the
 // lane whose position in its quad is t keeps them: after t = 0..3, kept[i] = the row's sum of tile
 // 4 bank + (lane & 3) = tile (lane & 15)
@@ -842,10 +936,6 @@ __device__ __forceinline__ float sin_reduced(float y) {
     return parity ? -p : p;
 }
 
-// exp for log-domain bookkeeping where ~2e-6 relative error is immaterial (segmentation
-// log-probabilities, asserted to 1e-4): v_exp_f32 on x * log2(e)
-__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
 // 24 encoded features of this lane group (layout: nerf_layout.h).
 __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[64]) {
 #pragma clang fp contract(off)
@@ -903,11 +993,13 @@ __device__ __forceinline__ float mean_distance(const Gaussian& a, const Gaussian
 // compositing of one 16-sample chunk (nerf/model.py:438-469, :660-663), shared by the fused
 // inference kernel and the stand-alone compositing kernel of the training path
 // ---------------------------------------------------------------------------------------------
+constexpr float kSegBias = 100.0f;      // exponent bias of the segmentation sums (composite_chunk)
 struct RayAccum {
     float carry;                // prod (alpha_i + 1e-10) over the finished chunks of the ray
     float rgb0, rgb1, rgb2;
     // running log-sum-exp over the ray's samples of ONE output slot per lane: lane (j, g) owns
-    // slot i = j of its lane group, i.e. output n = 16 (j >> 2) + 4 g + (j & 3)
+    // slot i = j of its lane group, i.e. output n = 16 (j >> 2) + 4 g + (j & 3); in base 2: the value is
+    // (seg_m + log2(seg_s) - kSegBias) ln 2 (composite_chunk)
     float seg_m, seg_s;
     __device__ __forceinline__ void reset() {
         carry = 1.0f;
@@ -949,48 +1041,48 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
 
     // colors: registers y, z, w of tile 0 are channels 3 g, 3 g + 1, 3 g + 2 of this lane group (nerf_layout.h:
     // color_slot) — all of them for the reference's 3 channels on lane group 0, harmless where the network has none
-    const float cr = w * (1.0f / (1.0f + expf(-out[0].y)));
-    const float cg = w * (1.0f / (1.0f + expf(-out[0].z)));
-    const float cb = w * (1.0f / (1.0f + expf(-out[0].w)));
+    // (sigmoid: v_rcp_f32, 1 ulp, for the IEEE division's ten instructions)
+    const float cr = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].y));
+    const float cg = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].z));
+    const float cb = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].w));
     acc.rgb0 += row_sum(cr);
     acc.rgb1 += row_sum(cg);
     acc.rgb2 += row_sum(cb);
 
     if (kSeg && a.seg != nullptr) {
-        // log_softmax over the class logits of this sample
+        // seg[class] = logsumexp over the ray's samples of log(w + 1e-10) + log_softmax(class logits) (nerf/model.py:
+        // 660-663), kept per owning lane as a running (max, sum) in base 2.  Every VALU instruction of this kernel is
+        // frame time (nothing executes beside an fp32 MFMA: NOTES.md section R6d), so the chunk's part is written for
+        // few of them: logits times log2(e) once, v_exp / v_log directly, ONE stabiliser for the whole chunk — B = the
+        // largest log2(w + 1e-10) of its samples, an upper bound of every term since log-probabilities are <= 0 —
+        // instead of a row maximum per class, and the 16 sums over the samples as one reduce-scatter butterfly.  A
+        // term enters as 2^(v - B + kSegBias): with the bias a class's sum underflows only when its probability is
+        // below 2^-220 in every sample of weight (a logit gap of 150), where the reference, which takes the maximum
+        // per class, would still return that -150; nothing a network trained with this loss produces.
+        constexpr float kLog2e = 1.4426950408889634f;
+        float mv[16];                               // class logits in base 2, -inf in the slots that hold none
         float m = -__builtin_inff();
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r, a)) m = __builtin_fmaxf(m, out[T][r]);
+            for (int r = 0; r < 4; ++r) {
+                mv[4 * T + r] = is_seg_slot(T, g, r, a) ? out[T][r] * kLog2e : -__builtin_inff();
+                m = __builtin_fmaxf(m, mv[4 * T + r]);
+            }
         m = group_max(m);
         float z = 0.f;
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (is_seg_slot(T, g, r, a)) z += exp_fast(out[T][r] - m);
+        for (int i = 0; i < 16; ++i) z += __builtin_amdgcn_exp2f(mv[i] - m);
         z = group_sum(z);
-        const float logz = logf(z);
-        const float lw = logf(w + 1e-10f);
-        // log-sum-exp over the 16 samples of the chunk per slot (row reductions), then merged
-        // into the owning lane's running (max, sum)
-        float cm = 0.f, cs = 0.f;
+        const float lw = ok ? __builtin_amdgcn_logf(w + 1e-10f) : -__builtin_inff();       // v_log_f32: log2
+        const float bound = row_max(lw);            // lane 0 of a chunk is always valid: finite
+        const float shift = ((lw - m) - __builtin_amdgcn_logf(z)) + (kSegBias - bound);    // -inf on a padded sample
+        float e[16];
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = ok ? lw + ((out[T][r] - m) - logz) : -__builtin_inff();
-                const float vm = row_max(v);              // lane 0 of a chunk is always valid
-                const float ve = row_sum(exp_fast(v - vm));
-                if (j == 4 * T + r) {
-                    cm = vm;
-                    cs = ve;
-                }
-            }
-        const float nm = __builtin_fmaxf(acc.seg_m, cm);
-        acc.seg_s = acc.seg_s * exp_fast(acc.seg_m - nm) + cs * exp_fast(cm - nm);
+        for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(mv[i] + shift);
+        const float cs = row_scatter_sum16(e, lane);       // lane j: slot j of its lane group, over the chunk's samples
+        const float nm = __builtin_fmaxf(acc.seg_m, bound);
+        acc.seg_s = acc.seg_s * __builtin_amdgcn_exp2f(acc.seg_m - nm) + cs * __builtin_amdgcn_exp2f(bound - nm);
         acc.seg_m = nm;
     }
     return w;
@@ -1018,7 +1110,7 @@ __device__ __forceinline__ void store_ray(const NerfHipRenderArgs& a, int64_t lo
     if (kSeg && a.seg != nullptr) {
         // the wave's 64 lanes cover n = 0..63 once: the class values leave in one store
         const int j = lane & 15, g = lane >> 4;
-        const float mine = acc.seg_m + logf(acc.seg_s);
+        const float mine = ((acc.seg_m + __builtin_amdgcn_logf(acc.seg_s)) - kSegBias) * 0.6931471805599453f;
         const int n = 16 * (j >> 2) + 4 * g + (j & 3);
         const Shape sh = shape_of(a);
         const int row = row_of_slot(n, sh);

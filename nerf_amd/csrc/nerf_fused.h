@@ -112,17 +112,6 @@ __device__ __forceinline__ void normalize_tile(f32x4& x, const LazyNorm& n, int 
     normalize_tile<kTrain, kPacked, kOrder>(x, n, T, n.gam[T], n.bet[T]);
 }
 
-// "1 MFMA, then `valu` VALU instructions", 7 times: spreads a region's VALU work over the gaps of
-// its 7 MFMAs (left alone, the scheduler parks it behind the last MFMA)
-template <int kValu>
-__device__ __forceinline__ void interleave_7() {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, kValu, 0);    // VALU
-    }
-}
-
 // Moments -> the deferred normalisation of `raw` (the layer's finished accumulators).
 // var = E[x^2] - mean^2 cancels when |mean| >> std, so whenever the mean carries more than 3/4 of
 // the second moment in ANY sample of the wave, a second pass (the two-pass variance) is taken instead

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "nerf_device.h"
 #include "nerf_fused.h"
 
@@ -95,17 +97,17 @@ __device__ __forceinline__ void layer_fused(FwdPipe& pipe, f32x4 (&in)[16], f32x
             out[2 * tp + 1] = mfma4(a1.z, b2, out[2 * tp + 1]);
             out[2 * tp] = mfma4(a0.w, b3, out[2 * tp]);
             out[2 * tp + 1] = mfma4(a1.w, b3, out[2 * tp + 1]);
-            // VALU riding in this group's MFMA shadow (same scheduling region as the 7 MFMAs):
+            // VALU riding behind this group's MFMAs (same scheduling region; NOT dealt out over the MFMA gaps: nothing
+            // executes beside an fp32 MFMA — NOTES.md section R6d — and bunched it costs fewer MFMA <-> VALU turn-arounds,
+            // 360.4 against 361.3 ms per frame):
             if (kNormIn && tp == 1 && t + 1 < KT) {
                 normalize_tile<kTrain>(in[t + 1], norm, t + 1, ga, be);
-                interleave_7<2>();
             }
             if (t == KT - 1 && tp >= 1) {         // tile pair finished one group ago
                 mom.add(out[2 * tp - 2]);
                 mom.add(out[2 * tp - 1]);
                 in[2 * tp - 2] = out[2 * tp - 2];
                 in[2 * tp - 1] = out[2 * tp - 1];
-                interleave_7<4>();
             }
             __builtin_amdgcn_sched_barrier(0);   // keep groups apart (else reads re-issue just in time)
         }
@@ -188,7 +190,7 @@ __device__ __forceinline__ void layer_fused_n(Pipe& pipe, f32x4 (&in)[16], f32x4
     mom.reset();
     f32x4 a[2][2];
     f32x4 ga, be;
-    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    __builtin_amdgcn_s_setprio(Pipe::kPrioMfma);
     const f32x4* st = pipe.open_stage();
     a[0][0] = st[0];
     a[0][1] = st[64];
@@ -225,14 +227,12 @@ __device__ __forceinline__ void layer_fused_n(Pipe& pipe, f32x4 (&in)[16], f32x4
         out[T1] = mfma4(a1.w, b3, out[T1]);
         if (kNormIn && lp == 1 && k + 1 < KG) {
             normalize_tile<kTrain>(in[k + 1], norm, k + 1, ga, be);
-            interleave_7<2>();
         }
         if (k == KG - 1 && lp >= 1) {             // tile pair finished one group ago
             mom.add(out[2 * lp - 2]);
             mom.add(out[2 * lp - 1]);
             in[2 * lp - 2] = out[2 * lp - 2];
             in[2 * lp - 1] = out[2 * lp - 1];
-            interleave_7<4>();
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -240,14 +240,14 @@ __device__ __forceinline__ void layer_fused_n(Pipe& pipe, f32x4 (&in)[16], f32x4
     mom.add(out[NT - 1]);
     in[NT - 2] = out[NT - 2];
     in[NT - 1] = out[NT - 1];
-    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+    __builtin_amdgcn_s_setprio(Pipe::kPrioValu);
 }
 
 // Layer 5 of a narrow network (16 NT -> 64 padded): NT / 4 stages of 4 k-groups x 4 out tiles.
 template <int NT, bool kTrain, class Pipe>
 __device__ __forceinline__ void layer_out_n(Pipe& pipe, f32x4 (&in)[16], f32x4 (&acc)[4], const LazyNorm& norm) {
     normalize_tile<kTrain>(in[0], norm, 0);
-    __builtin_amdgcn_s_setprio(NERF_PRIO_MFMA);
+    __builtin_amdgcn_s_setprio(Pipe::kPrioMfma);
 #pragma unroll
     for (int s = 0; s < NT / 4; ++s) {
         const f32x4* st = pipe.open_stage();
@@ -275,7 +275,7 @@ __device__ __forceinline__ void layer_out_n(Pipe& pipe, f32x4 (&in)[16], f32x4 (
             if (t + 1 < NT) normalize_tile<kTrain>(in[t + 1], norm, t + 1);
         }
     }
-    __builtin_amdgcn_s_setprio(NERF_PRIO_VALU);
+    __builtin_amdgcn_s_setprio(Pipe::kPrioValu);
 }
 
 
@@ -357,21 +357,33 @@ __device__ __forceinline__ void layer_out_h(Pipe& pipe, f32x4 (&in)[16], f32x4 (
 // per-sample VALU phases (encoding, LayerNorm finishing, compositing) need a second partner to hide under.
 template <bool kPerSample, int NT>
 constexpr bool three_per_cu() { return NT < 16 && !kPerSample; }
+// The render-only kernel at 4 register tiles keeps the WHOLE weight image in LDS (nerf_device.h: ResidentPipe): one
+// workgroup of 16 waves per CU, 128.25 KiB, no barrier after the prologue; a wave owns a ray as before.
+template <bool kTrain, bool kHalf, bool kPerSample, int NT>
+constexpr bool resident_weights() { return NT == 4 && !kHalf && !kPerSample && !kTrain; }
+constexpr int kResidentWaves = 16;
+constexpr int kResidentLdsBytes = Narrow<4>::kStages * kStageBytes + kSmallLdsBytes;
+static_assert(kResidentLdsBytes <= 160 * 1024, "the resident image and the small image share one CU's LDS");
 
 template <bool kTrain, bool kHalf, bool kPerSample = false, int NT = 16>
-__global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void nerf_render_fwd_kernel(const KernelArgs ka) {
+__global__ __launch_bounds__((resident_weights<kTrain, kHalf, kPerSample, NT>() ? 64 * kResidentWaves : 256),
+                             (resident_weights<kTrain, kHalf, kPerSample, NT>() ? 1 : three_per_cu<kPerSample, NT>() ? 3 : 2))
+void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     static_assert(NT != 4 || !kHalf, "4 register tiles: fp32 arithmetic only (the split-precision arithmetic runs at 8 or 16)");
     // saved x_hat rows of a training forward: 128 wide for the narrow networks at EITHER compute width (the weight
     // gradient runs at 8 register tiles): a 4-tile forward writes tiles 4 .. 7 as zeros
     constexpr int kSaveTiles = NT == 4 ? 8 : NT;
     typedef Narrow<NT> N;
+    constexpr bool kResident = resident_weights<kTrain, kHalf, kPerSample, NT>();
+    constexpr int kWaves = kResident ? kResidentWaves : kWavesPerWg;
     constexpr int kDepth = three_per_cu<kPerSample, NT>() ? 2 : 3;
-    constexpr int kRingB = kDepth * kStageBytes, kLdsB = kRingB + kSmallLdsBytes;
+    constexpr int kRingB = (kResident ? N::kStages : kDepth) * kStageBytes, kLdsB = kRingB + kSmallLdsBytes;
     // (the split-precision kernel's LDS stash of per-lane state exists for the 256-register full-width kernel; at
     //  8 register tiles the state stays in registers)
     constexpr bool kStash = kHalf && !kTrain && kDepth == 3;
-    typedef WeightPipe<(kHalf && NT == 8 ? kNarrowH8Stages : N::kStages), kDepth> Pipe;
+    typedef typename std::conditional<kResident, ResidentPipe<N::kStages, kWaves>,
+                                      WeightPipe<(kHalf && NT == 8 ? kNarrowH8Stages : N::kStages), kDepth>>::type Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -382,16 +394,18 @@ __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void
 
     // small image -> LDS (once per workgroup)
     {
-        stage_small_image(a.packed + (kHalf ? kHSmallOffset : kBlobFloats), (float*)(smem + kRingB));
+        stage_small_image<64 * kWaves>(a.packed + (kHalf ? kHSmallOffset : kBlobFloats), (float*)(smem + kRingB));
     }
     const float* small = (const float*)(smem + kRingB);
 
     Pipe pipe;
     pipe.init(a.packed + (kHalf ? (NT == 16 ? kHBlobOffset : kNarrowH8Offset)
                                 : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
-    pipe.issue();
-    if (kDepth == 3) pipe.issue();
-    __syncthreads();          // small image visible (this also drains the two DMA stages once)
+    if constexpr (!kResident) {
+        pipe.issue();
+        if (kDepth == 3) pipe.issue();
+        __syncthreads();      // small image visible (this also drains the two DMA stages once)
+    }                         // (resident: init() loaded the image and ended in the barrier)
 
     f32x4 X[16], Y[16];         // X: a layer's input tiles (B operands), Y: its accumulators (the first NT of them)
     float* const ws = a.train_workspace;
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(256, (three_per_cu<kPerSample, NT>() ? 3 : 2)) void
     // work here is one (ray, chunk) item per wave — a 512-ray batch then fills all 2,048 waves
     // instead of 512 of them — and the network outputs / distances are saved for it.
     for (int64_t grp = blockIdx.x; grp < ka.groups; grp += gridDim.x) {
-        const int64_t unit = grp * kWavesPerWg + wave;
+        const int64_t unit = grp * kWaves + wave;
         const int64_t slot = kTrain ? unit / chunks : unit;      // padded ray slot (workspace rows)
         int64_t local = slot;
         const bool ray_ok = local < a.n_rays;
@@ -1099,14 +1113,19 @@ int nerf_hip_render_forward(const NerfHipRenderArgs* args, void* stream) {
     // LDS: three-slot ring + small image (+ the split-precision kernel's stash); the render-only narrow kernels run a
     // two-slot ring without a stash, three workgroups per CU
     const bool three = is_narrow && !ps;
-    const int lds_bytes = three ? 2 * kStageBytes + kSmallLdsBytes : (half ? kLdsBytesHalf : kLdsBytes);
+    // ... and the render-only kernel at 4 tiles keeps its whole image resident: ONE workgroup of 16 waves per CU, a ray
+    // per wave (resident_weights above)
+    const bool resident = nt == 4 && !half && !ps && !train;
+    const int waves = resident ? kResidentWaves : kWavesPerWg;
+    if (resident) ka.groups = (a.n_rays + waves - 1) / waves;
+    const int lds_bytes = resident ? kResidentLdsBytes : three ? 2 * kStageBytes + kSmallLdsBytes : (half ? kLdsBytesHalf : kLdsBytes);
     rc = nerf_common::ensure_dynamic_lds((const void*)kernel, lds_bytes, device, done_mask);
     if (rc) return rc;
-    int64_t grid = (int64_t)cus * (three ? 3 : 2);   // workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs; narrow: 48.25 KiB, <= 168)
+    int64_t grid = (int64_t)cus * (resident ? 1 : three ? 3 : 2);   // workgroups per CU (<= 72.4 KiB LDS, <= 256 VGPRs; narrow: 48.25 KiB, <= 168)
     if (grid > ka.groups) grid = ka.groups;
     hipStream_t st = (hipStream_t)stream;
     nerf_common::Timing::before(st);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, ka);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), lds_bytes, st, ka);
     nerf_common::Timing::after(st, NERF_HIP_TIMING_FORWARD);
     if (train) {
         nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_COMPOSITE_FORWARD);
