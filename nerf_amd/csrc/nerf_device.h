@@ -913,27 +913,27 @@ __device__ __forceinline__ Gaussian frustum(const Ray& r, float t0, float t1, fl
 
 // sin(y) for |y| up to ~2e5 rad (the encoding's largest scale times the far plane) to ~1 ulp
 // (max |error| 1.3e-7 against fp64 over +-2e5): half-turn reduction n = rint(y / pi),
-// r = y - n pi by three FMAs against pi split into three fp32 terms (Cody-Waite; each FMA rounds
+// r = y - n pi by two FMAs against pi split into two fp32 terms (Cody-Waite; each FMA rounds
 // once, and the first one cancels exactly the leading bits, so r carries ~1e-7 absolute error —
-// the same as the fp64 reduction it replaces, measured on 4e6 arguments), then an odd degree-11
-// minimax polynomial on [-pi/2, pi/2] (3e-11 fit error, evaluated as r + r^3 s(r^2) so the
-// leading term is exact) and the (-1)^n sign.  ~15 full-rate issue slots against ~100+ for the
-// general-purpose sinf with its Payne-Hanek path.
+// the same as the fp64 reduction it replaces, measured on 4e6 arguments; a third term of pi would add
+// n 3.4e-15, 2e-10 at the top of the range), then an odd degree-9 minimax polynomial on [-pi/2, pi/2]
+// (4.6e-9 fit error, 1.0e-7 evaluated in fp32 — the degree-11 one: 1.2e-7 —, as r + r^3 s(r^2) so the
+// leading term is exact) and the (-1)^n sign.  13 issue slots against ~100+ for the general-purpose sinf
+// with its Payne-Hanek path; every one of them is frame time in the fp32 kernels (NOTES.md section R6d).
 // No fp64 anywhere in the kernels (the 24 reductions per sample used to be v_cvt / v_mul / v_rndne /
 // v_fma _f64, quarter rate).
 __device__ __forceinline__ float sin_reduced(float y) {
     const float n = __builtin_rintf(y * 0.318309886f);
     float r = __builtin_fmaf(-n, 3.1415927410125732f, y);
     r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
-    r = __builtin_fmaf(-n, -3.4302490200117637e-15f, r);
-    const int parity = (int)n & 1;
+    // (-1)^n as a sign bit for an exclusive-or: a shift and a v_xor for the v_and, v_cmp and v_cndmask of a select
+    const uint32_t sign = (uint32_t)(int)n << 31;
     const float u = r * r;
-    float s = __builtin_fmaf(u, -2.3794713703943473e-08f, 2.7518855647935822e-06f);
-    s = __builtin_fmaf(u, s, -0.00019840702862741812f);
-    s = __builtin_fmaf(u, s, 0.008333329264456273f);
-    s = __builtin_fmaf(u, s, -0.16666666541439012f);
+    float s = __builtin_fmaf(u, 2.5999029276135843e-06f, -0.00019806546333711594f);
+    s = __builtin_fmaf(u, s, 0.008333016186952591f);
+    s = __builtin_fmaf(u, s, -0.16666656732559204f);
     const float p = __builtin_fmaf(r * u, s, r);
-    return parity ? -p : p;
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) ^ sign);
 }
 
 // 24 encoded features of this lane group (layout: nerf_layout.h).
@@ -946,7 +946,7 @@ __device__ __forceinline__ void encode(const Gaussian& gs, int g, float (&act)[6
         const float scale = base * (float)(1 << (p / 3));
         const float y = gs.mean[p % 3] * scale;
         const float yv = gs.cov[p % 3] * (scale * scale);
-        const float damp = expf(-0.5f * yv);
+        const float damp = __builtin_amdgcn_exp2f(yv * -0.7213475204444817f);      // exp(-yv / 2): v_exp_f32 on -yv / (2 ln 2), |error| < 1 ulp + 2e-8
         act[p] = damp * sin_reduced(y);
         act[12 + p] = damp * sin_reduced(y + half_pi);
     }
@@ -968,7 +968,7 @@ __device__ __forceinline__ void encode_n(const Gaussian& gs, int g, int per, flo
             for (int c = 0; c < 3; ++c) {
                 const float y = gs.mean[c] * scale;
                 const float yv = gs.cov[c] * (scale * scale);
-                const float damp = expf(-0.5f * yv);
+                const float damp = __builtin_amdgcn_exp2f(yv * -0.7213475204444817f);      // exp(-yv / 2): v_exp_f32 on -yv / (2 ln 2), |error| < 1 ulp + 2e-8
                 sn[c] = damp * sin_reduced(y);
                 cs[c] = damp * sin_reduced(y + half_pi);
             }
@@ -1032,7 +1032,8 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
         dens = dens + nerf_rng::normal(a.rng_seed, rng_offset_of(a), (uint64_t)(a.ray_begin + local),
                                        (uint32_t)s, 1u) * a.density_noise_std;
     }
-    const float alpha = ok ? expf(-__builtin_fmaxf(dens, 0.f) * dist) : 1.0f;
+    // (exp as v_exp_f32 on x log2(e): the product's rounding adds |x| 6e-8 of relative error, 2e-8 absolute at most)
+    const float alpha = ok ? __builtin_amdgcn_exp2f(__builtin_fmaxf(dens, 0.f) * dist * -1.4426950408889634f) : 1.0f;
     const float prod = row_prefix_prod(ok ? alpha + 1e-10f : 1.0f);
     const float t_excl = acc.carry * row_shift_up(1.0f, prod);
     const float w = ok ? (1.0f - alpha) * t_excl : 0.f;
@@ -1042,9 +1043,9 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
     // colors: registers y, z, w of tile 0 are channels 3 g, 3 g + 1, 3 g + 2 of this lane group (nerf_layout.h:
     // color_slot) — all of them for the reference's 3 channels on lane group 0, harmless where the network has none
     // (sigmoid: v_rcp_f32, 1 ulp, for the IEEE division's ten instructions)
-    const float cr = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].y));
-    const float cg = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].z));
-    const float cb = w * __builtin_amdgcn_rcpf(1.0f + expf(-out[0].w));
+    const float cr = w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(out[0].y * -1.4426950408889634f));
+    const float cg = w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(out[0].z * -1.4426950408889634f));
+    const float cb = w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(out[0].w * -1.4426950408889634f));
     acc.rgb0 += row_sum(cr);
     acc.rgb1 += row_sum(cg);
     acc.rgb2 += row_sum(cb);

@@ -67,7 +67,7 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
     largest of four fp32 evaluations) of the fp64 or the fp32 oracle on the kernel's gates, relative to its largest
     element.  ``gates``: the kernel's six gates when the caller read them itself (a loss without compositing has no
     density gate in the workspace).
-    Returns (flips, total, worst error, the fp32 oracle's gradients on its OWN gates)."""
+    Returns (flips, total, worst error, the fp32 oracle's gradients on its OWN gates, and on the KERNEL's gates)."""
     if gates is None:
         gates = kernel_gates(model, params, n_rays, num_samples)
     own = []
@@ -105,4 +105,4 @@ def check(model, params, n_rays, num_samples, loss_fn, grad_bound=GRAD_BOUND, fl
     print(f"[{tag}] worst relative gradient error on the kernel's gates {worst:.2e} (fp32 oracle, same gates: "
           f"{max(rel_err(inst[k], ref64[k]) for inst in instances for k in ref64):.2e}); {flips} of {total} gates differ from the oracle's own "
           f"(against the oracle on ITS gates: {max(rel_err(p.grad.cpu(), plain[k]) for k, p in model.named_parameters()):.2e})")
-    return flips, total, worst, plain
+    return flips, total, worst, plain, ref32

@@ -85,7 +85,7 @@ def test_training_step_vs_reference(dev, name, scale):
     # gate-aware (tests/gate_aware.py): the oracle on the gates the kernels ran with agrees to arithmetic accuracy whatever
     # the fixture's borderline gates do; where no gate differs from the oracle's own, the REFERENCE's gradients do too
     import gate_aware
-    flips, total, _, _ = gate_aware.check(
+    flips, total, _, _, _ = gate_aware.check(
         model, golden_params(scale), g["rays_o"].shape[0], 64,
         lambda p, gates, record: O.training_loss(
             p, CFG, *(gate_aware.caster(p)(g[k]) for k in ("rays_o", "rays_d")), 64,

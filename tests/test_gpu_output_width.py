@@ -323,16 +323,19 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
     # are counted, and where there is none the reference's own gradients are held at the same bound.
     import gate_aware
     cfg32 = dict(O.default_config(), **kw)
-    flips, total, _, plain = gate_aware.check(
+    flips, total, _, plain, on_kernel_gates = gate_aware.check(
         model, params, g["rays_o"].shape[0], 32,
         lambda p, gates, record: O.training_loss(
             p, cfg32, *(gate_aware.caster(p)(g[k]) for k in ("rays_o", "rays_d")), 32,
             *(gate_aware.caster(p)(g[k]) for k in ("target", "u", "noise")), float(g["noise_std"]), gates=gates,
             record=record), tag=tag + " " + precision)
+    # what the flipped gates themselves move: the oracle on the kernel's gates against the oracle on its own (one flipped
+    # gate is worth 1e-4 ... 4e-4 of a tensor's largest element here, whichever arithmetic flips it)
     for k, p in model.named_parameters():
         assert rel_err(plain[k], g["grad." + k]) <= 1e-5, k          # the oracle IS the reference here
         e = rel_err(p.grad.cpu(), g["grad." + k])
-        assert e <= 5e-6 + 8 * floor + 2e-4 * flips, (k, e, floor, flips)
+        moved = rel_err(on_kernel_gates[k], plain[k]) if flips else 0.0
+        assert e <= 5e-6 + 8 * floor + 1.5 * moved, (k, e, floor, flips, moved)
 
 
 def test_shapes_the_kernels_do_not_take_are_refused():
