@@ -160,9 +160,12 @@ constexpr NormDivisor kFullWidth = {1.0f / 256.0f, 256};
 // of stage s leaves its 4 pieces in flight.  2 (the narrow inference kernels, which then fit THREE workgroups of 48 KiB
 // on a CU): the DMA of stage s + 1 is issued when stage s opens and has that stage's MFMAs to land — nothing of it may
 // still fly at the next hand-over (vmcnt(0 + younger)).
-template <int kStagesInImage, int kDepth = 3>
+// kSkippable: the stream can leave out ONE stage of the image per pass (skip_stage, set by the kernel before the first
+// issue(); -1: none) — the 4-tile kernels run layer 0 of a network with few encoding scales from one stage of two.
+template <int kStagesInImage, int kDepth = 3, bool kSkippable = false>
 struct WeightPipe {
     static constexpr int kRingDepth = kDepth;
+    int skip_stage;             // (kSkippable only)
     static constexpr int kPrioMfma = NERF_PRIO_MFMA, kPrioValu = NERF_PRIO_VALU;
     const char* blob;           // packed image, stage 0
     char* ring;                 // LDS ring base
@@ -176,6 +179,7 @@ struct WeightPipe {
         blob = (const char*)image;
         ring = lds_ring;
         issue_stage = issue_slot = read_slot = 0;
+        skip_stage = -1;
         wave = w;
         lane = l;
     }
@@ -218,6 +222,7 @@ struct WeightPipe {
                 : "memory");
         }
         issue_stage = (issue_stage + 1 == kStagesInImage) ? 0 : issue_stage + 1;
+        if (kSkippable && issue_stage == skip_stage) ++issue_stage;       // (never the image's last stage)
         issue_slot = (issue_slot + 1 == kDepth) ? 0 : issue_slot + 1;
     }
 
@@ -269,6 +274,7 @@ struct ResidentPipe {
     static constexpr int kPrioMfma = NERF_PRIO_MFMA, kPrioValu = NERF_PRIO_VALU;
     char* image;                // LDS copy of the packed image
     int read_stage;             // stage the next open_stage() hands out (cyclic)
+    int skip_stage;             // a stage every pass leaves out (-1: none; WeightPipe: kSkippable)
     int lane;
 
     // Called by every wave of the workgroup; ends in a barrier.  4 KiB chunk c of the image (4 DMA pieces, as
@@ -276,6 +282,7 @@ struct ResidentPipe {
     __device__ __forceinline__ void init(const void* packed_image, char* lds, int w, int l) {
         image = lds;
         read_stage = 0;
+        skip_stage = -1;
         lane = l;
         constexpr int kChunks = kStagesInImage * kStageBytes / 4096;
 #pragma unroll 1
@@ -307,6 +314,7 @@ struct ResidentPipe {
     __device__ __forceinline__ const f32x4* open_stage() {
         const f32x4* p = (const f32x4*)(image + read_stage * kStageBytes) + lane;
         read_stage = (read_stage + 1 == kStagesInImage) ? 0 : read_stage + 1;
+        if (read_stage == skip_stage) ++read_stage;
         return p;
     }
     __device__ __forceinline__ void prefetch_next() {}

@@ -246,6 +246,13 @@ __host__ __device__ inline int layer0_source_feature(int t, int g, int r) {
 // the NARROW kernels (nerf_layout.h: Narrow<NT>), whose frame time is front-end VALU work, spread the scales a
 // network HAS over the four lane groups — scales_per_group — and skip the pairs beyond them.
 __host__ __device__ inline int scales_per_group(int scales) { return (scales + 3) / 4; }
+// DENSE layer 0 of the kernels at 4 register tiles, for networks of at most 8 encoding scales (scales_per_group <= 2):
+// the 12 slots a lane group then fills — 6 sine slots q = 0..5 and 6 shifted ones q = 12..17 of the layout above —
+// move together into dense slots d = 0..11 = three k-groups, and layer 0 is ONE stage of four k-groups (the fourth
+// zero) where the sparse layout needs the two stages of eight (nerf_layout.h: Narrow<4>; the second is skipped).
+// Old slot of dense slot d, or -1 for the padding slots d >= 12:
+__host__ __device__ inline bool layer0_dense(int nt, int per) { return nt == 4 && per <= 2; }
+__host__ __device__ inline int layer0_dense_source_slot(int d) { return d < 6 ? d : (d < 12 ? d + 6 : -1); }
 __host__ __device__ inline int layer0_source_feature(int t, int g, int r, int scales, int per = 4) {
     const int q = 4 * t + r;
     const int part = q / 12, p = q % 12;

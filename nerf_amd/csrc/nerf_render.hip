@@ -383,7 +383,7 @@ void nerf_render_fwd_kernel(const KernelArgs ka) {
     //  8 register tiles the state stays in registers)
     constexpr bool kStash = kHalf && !kTrain && kDepth == 3;
     typedef typename std::conditional<kResident, ResidentPipe<N::kStages, kWaves>,
-                                      WeightPipe<(kHalf && NT == 8 ? kNarrowH8Stages : N::kStages), kDepth>>::type Pipe;
+                                      WeightPipe<(kHalf && NT == 8 ? kNarrowH8Stages : N::kStages), kDepth, NT == 4>>::type Pipe;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const NerfHipRenderArgs& a = ka.a;
     const int lane = threadIdx.x & 63;
@@ -401,6 +401,10 @@ void nerf_render_fwd_kernel(const KernelArgs ka) {
     Pipe pipe;
     pipe.init(a.packed + (kHalf ? (NT == 16 ? kHBlobOffset : kNarrowH8Offset)
                                 : (NT == 16 ? 0 : (NT == 8 ? kNarrow8Offset : kNarrow4Offset))), smem, wave, lane);
+    // 4 tiles, at most 8 encoding scales: layer 0 from ONE stage, the image's second stage left out (nerf_layout.h:
+    // layer0_dense)
+    const bool dense0 = NT == 4 && layer0_dense(4, ka.enc_per);
+    if (NT == 4 && dense0) pipe.skip_stage = 1;
     if constexpr (!kResident) {
         pipe.issue();
         if (kDepth == 3) pipe.issue();
@@ -523,10 +527,18 @@ void nerf_render_fwd_kernel(const KernelArgs ka) {
             } else if constexpr (NT < 16) {
                 // ---- a narrow network at its own cost (nerf_layout.h: Narrow<NT>) ----
                 Moments mom;
-#pragma unroll
-                for (int t = kStagesL0; t < N::kKGroups0; ++t) X[t] = f32x4{0.f, 0.f, 0.f, 0.f};    // zero-padded k-groups
                 load_bias_n<NT>(small, g, Y);
-                layer_fused_n<NT, N::kKGroups0, false, kTrain>(pipe, X, Y, norm, mom);
+                if (NT == 4 && dense0) {
+                    // dense slots d = 4 t + r <- old slots (layer0_dense_source_slot): 0..5, then 12..17
+                    X[1].z = X[3].x, X[1].w = X[3].y;
+                    X[2] = f32x4{X[3].z, X[3].w, X[4].x, X[4].y};
+                    X[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    layer_fused_n<NT, 4, false, kTrain>(pipe, X, Y, norm, mom);
+                } else {
+#pragma unroll
+                    for (int t = kStagesL0; t < N::kKGroups0; ++t) X[t] = f32x4{0.f, 0.f, 0.f, 0.f};    // zero-padded k-groups
+                    layer_fused_n<NT, N::kKGroups0, false, kTrain>(pipe, X, Y, norm, mom);
+                }
                 norm = finish_moments<kTrain, Moments, NT>(mom, X, small, g, xrow + ka.save.xhat[0], rstd_p + ka.save.rstd[0], ka.norm);
 #pragma unroll 1
                 for (int L = 1; L <= 4; ++L) {
@@ -826,7 +838,13 @@ __global__ void nerf_pack_kernel(const PackArgs pa) {
         const int sh = eight ? Narrow<8>::kStagesHid : Narrow<4>::kStagesHid;
         if (stage < s0) {                                           // layer 0: quads numbered k-group * NT + out tile
             const int qq = stage * 16 + quad, k = qq / nt, T = qq % nt;
-            v = k < kStagesL0 ? pa.w0(16 * T + row, k, g, r, scales_per_group(pa.enc_in / 6)) : 0.f;
+            const int per = scales_per_group(pa.enc_in / 6);
+            if (layer0_dense(nt, per)) {                            // dense slots (nerf_layout.h): all of it in stage 0
+                const int q = layer0_dense_source_slot(4 * k + r);
+                v = q >= 0 ? pa.w0(16 * T + row, q / 4, g, q % 4, per) : 0.f;
+            } else {
+                v = k < kStagesL0 ? pa.w0(16 * T + row, k, g, r, per) : 0.f;
+            }
         } else if (stage < s0 + 4 * sh) {                           // layers 1..4
             const int L = 1 + (stage - s0) / sh;
             const int qq = ((stage - s0) % sh) * 16 + quad, k = qq / nt, T = qq % nt;
