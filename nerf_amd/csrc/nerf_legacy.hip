@@ -576,8 +576,10 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     for (int T = 0; T < 16; ++T) mom.template add<kOrderReluNorm>(Y[T]);
                     if (p == 3) {                 // density head on x'_7: the pairs L8's fused loop made of it
                         const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
+                        // (the lane group behind an optimisation barrier: the address hb + g is otherwise formed once per
+                        //  kernel and parked in scratch across the layers)
                         if constexpr (kTrain) dens = head_layer_hb(pipe, hb[g], xb_hi, xb_lo).x * kUn;
-                        else dens = head_layer_h<false, kTrain>(pipe, hb[g], X, norm).x * kUn;
+                        else dens = head_layer_h<false, kTrain>(pipe, hb[lane_offset((uint32_t)g)], X, norm).x * kUn;
                     }
                 }
                 norm = nerf_fused::finish_moments_at<kTrain, HMoments, kOrderReluNorm>(
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void nerf_legacy_fwd_h_kernel(const LegacyK
                     kRs, stat + ka.save.shift[la_ + 1]);
             }
             const f32x4* hb = (const f32x4*)(small + kWide * kLegacySmallPerLayer);
-            const f32x4 col = head_layer_h<true, kTrain>(pipe, hb[4 + g], X, norm) * kUn;
+            const f32x4 col = head_layer_h<true, kTrain>(pipe, hb[4 + (kTrain ? (uint32_t)g : lane_offset((uint32_t)g))], X, norm) * kUn;
             f32x4 out[4];
             out[0] = f32x4{dens, col.x, col.y, col.z};
             out[1] = out[2] = out[3] = f32x4{0.f, 0.f, 0.f, 0.f};
