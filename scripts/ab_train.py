@@ -12,7 +12,10 @@ dev = torch.device("cuda:0")
 out = {}
 for p in ("fp32", "f16x3"):
     out["legacy_" + p] = bench.legacy_train_step_timing(dev, train_precision=p, steps=8)["ms_per_step"]
-    out["main_" + p] = bench.train_step_timing(dev, train_precision=p)["ms_per_step"]
+    t = bench.train_step_timing(dev, train_precision=p)
+    out["main_" + p] = t["ms_per_step"]
+    for k in ("forward", "data_gradient", "weight_gradient"):
+        out["main_" + p + "_" + k] = t["kernels_ms"][k]
 print(json.dumps(out))
 """ % ROOT
 res = {l: [] for l in libs}
@@ -25,6 +28,8 @@ for r in range(rounds):
             print(out.stderr[-2000:])
             sys.exit(1)
         res[l].append(json.loads(lines[-1]))
-for key in ("legacy_fp32", "legacy_f16x3", "main_fp32", "main_f16x3"):
+keys = ["legacy_fp32", "legacy_f16x3", "main_fp32", "main_f16x3"]
+keys += [f"main_{p}_{k}" for p in ("fp32", "f16x3") for k in ("forward", "data_gradient", "weight_gradient")]
+for key in keys:
     for l, v in res.items():
-        print(f"{key:14s} {l:24s} ms: " + " ".join(f"{x[key]:.3f}" for x in v) + f"   min {min(x[key] for x in v):.3f}")
+        print(f"{key:28s} {l:24s} ms: " + " ".join(f"{x[key]:.3f}" for x in v) + f"   min {min(x[key] for x in v):.3f}")
