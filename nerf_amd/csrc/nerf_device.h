@@ -1071,11 +1071,18 @@ __device__ __forceinline__ float composite_chunk(const NerfHipRenderArgs& a, int
         constexpr float kLog2e = 1.4426950408889634f;
         float mv[16];                               // class logits in base 2, -inf in the slots that hold none
         float m = -__builtin_inff();
+        // (is_seg_slot with the lane group behind an optimisation barrier: the sixteen tests depend on nothing but the
+        //  lane and the launch, and hoisted out of the ray loop they live as sixteen lane masks in scalar registers —
+        //  spilled to vector-register lanes and read back with two v_readlane per use)
+        int g4 = 4 * g;
+        asm volatile("" : "+v"(g4));
+        const uint32_t bits0 = (uint32_t)a.reserved >> g4;      // tile 0: the class bits of this lane group's four slots
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mv[4 * T + r] = is_seg_slot(T, g, r, a) ? out[T][r] * kLog2e : -__builtin_inff();
+                const bool is_class = T == 0 ? ((bits0 >> r) & 1u) != 0 : 16 * T + r + g4 < a.num_outputs;
+                mv[4 * T + r] = is_class ? out[T][r] * kLog2e : -__builtin_inff();
                 m = __builtin_fmaxf(m, mv[4 * T + r]);
             }
         m = group_max(m);

@@ -138,7 +138,12 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
         // branch that is cold — the pre-LayerNorm activations of this network have |mean| well below std.
         // (the mask as integer arithmetic — sign bits of 16 T + r - (real - 4 g), ANDed onto the difference — not as
         //  compares: 4 NT lane masks in scalar registers are what the narrow kernels, at their register limit, lack)
-        const int lim = nd.real - 4 * g;
+        // (... and `lim` behind an optimisation barrier IN the branch: the compiler turns the sign-bit arithmetic back
+        //  into 4 NT compares, which depend on nothing but the lane and the launch and are hoisted to the top of the
+        //  kernel as 64 lane masks = 128 scalar registers, parked in vector-register lanes and crowding the values the
+        //  hot path needs out with them: 187 v_writelane in the prologue, ~95 v_readlane per 16-sample chunk)
+        int lim = nd.real - 4 * g;
+        asm volatile("" : "+v"(lim));
         float v = 0.f;
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
