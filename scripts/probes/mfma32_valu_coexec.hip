@@ -5,7 +5,11 @@
 //   part 1 (one wave per SIMD): 1 MFMA + k independent v_fma_f32 per gap, k = 0..8 -> cycles per gap, for the fp32
 //          16x16x4 MFMA and, as the control, the 32x32x16 f16 MFMA (where 4 fillers are free: valu_issue_cost.hip);
 //   part 2 (two waves per SIMD): waves 0-3 stream MFMAs, waves 4-7 stream v_fma_f32; each side alone and both
-//          together -> cycles for the same instruction counts.
+//          together -> cycles for the same instruction counts;
+//   part 3: the same with the VALU waves at s_setprio 2 (what the render kernels do) and 16 / 2 / 1 dependent chains.
+// Result (profiles/r06_h_mfma32_valu_coexec_probe.log, NOTES.md section R6d): beside the fp32 MFMA stream the VALU
+// wave makes NO progress at any priority (its time = the MFMA stream's + its own), beside the f16 stream it runs at
+// 0.8 of its own rate; a VALU instruction between two of the wave's own fp32 MFMAs costs 15 ticks, then 4.4 each.
 // Build: hipcc --offload-arch=gfx950 -O2 scripts/probes/mfma32_valu_coexec.hip -o /tmp/mfma32_valu_coexec
 #include <hip/hip_runtime.h>
 #include <stdint.h>

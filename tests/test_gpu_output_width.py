@@ -21,7 +21,11 @@ pytestmark = pytest.mark.gpu
 # output tile 0 (nerf_layout.h: color_slot), so 4 and 7 cross into lane groups 1 and 2 and the classes fill the slots
 # between them; 12 with 51 classes is the full 64-row tile; (0 classes, 4 colors) leaves a padding slot INSIDE the tile
 SHAPES = [(0, 256, 32), (7, 256, 32), (60, 256, 32), (50, 128, 32), (50, 256, 16), (7, 64, 16), (3, 40, 10),
-          (50, 256, 32, 1), (50, 256, 32, 4), (0, 256, 32, 4), (9, 128, 32, 7), (51, 256, 32, 12), (0, 64, 16, 1)]
+          (50, 256, 32, 1), (50, 256, 32, 4), (0, 256, 32, 4), (9, 128, 32, 7), (51, 256, 32, 12), (0, 64, 16, 1),
+          # hidden_size <= 64 with 16 / 12 / 4 encoding scales: the 4-tile kernels run layer 0 DENSE from one weight
+          # stage when a lane group evaluates at most two scales (encoding_size <= 16: the cases above, and 8 here) and
+          # from the two sparse stages otherwise (nerf_layout.h: layer0_dense)
+          (5, 64, 32), (4, 48, 24), (2, 32, 8)]
 
 
 def colors_of(shape):
