@@ -101,31 +101,42 @@ __device__ __forceinline__ void encode_direction(const Ray& ray, float dlen, con
 }
 
 // LayerNorm(256, eps 1e-5, affine) of relu(acc) -> act (the next layer's B operands).
-// Lane (j, g) holds features 16 T + 4 g + r of sample j in acc[T][r]; exact two-pass variance.
+// Lane (j, g) holds features 16 T + 4 g + r of sample j in acc[T][r].  Five VALU instructions per element (max, add,
+// fma | fma, fma) — this phase is frame time in full: nothing executes beside the fp32 MFMAs of the wave's SIMD partner
+// (NOTES.md section R6d; it was seven, with a two-pass variance and (a - mean) * rstd): one-pass moments, with the exact
+// two-pass variance as a wave-uniform fallback when the mean carries more than 3/4 of the second moment in any sample
+// (as nerf_fused.h: finish_moments_at; ReLU outputs of a zero-mean pre-activation have mean^2 = 0.32 E[a^2]).
 // kTrain: also saves a_hat = (relu(y) - mean) / std (row order), 1/std and `shift` = the a_hat of a closed
-// gate ((0 - mean) / std, rounded like a_hat), so that the backward reads the ReLU gate as a_hat > shift.
-// The subtraction and the product are monotonic, so a_hat >= shift always; where an OPEN gate (y > 0, y below
+// gate (fma(0, 1/std, shift) = shift exactly), so that the backward reads the ReLU gate as a_hat > shift.
+// The FMA is monotonic in relu(y), so a_hat >= shift always; where an OPEN gate (y > 0, y below
 // half an ulp of the mean) rounds onto `shift`, a_hat is moved one ulp up — the gate the backward sees is exact.
 template <bool kTrain>
 __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const float* small_l, int g,
                                                 float (&act)[64], float* xhat_row = nullptr,
                                                 float* rstd_p = nullptr, float* shift_p = nullptr) {
-    float sum = 0.f;
+    float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int T = 0; T < 16; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            act[4 * T + r] = __builtin_fmaxf(acc[T][r], 0.f);
-            sum += act[4 * T + r];
+            const float a = __builtin_fmaxf(acc[T][r], 0.f);
+            act[4 * T + r] = a;
+            sum += a;
+            sq = __builtin_fmaf(a, a, sq);
         }
     const float mean = group_sum(sum) * (1.0f / 256.0f);
-    float sq = 0.f;
+    const float ex2 = group_sum(sq) * (1.0f / 256.0f);
+    float var = ex2 - mean * mean;
+    if (__builtin_amdgcn_ballot_w64(mean * mean > 0.75f * ex2) != 0) {
+        float sq2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const float d = act[i] - mean;
-        sq = __builtin_fmaf(d, d, sq);
+        for (int i = 0; i < 64; ++i) {
+            const float d = act[i] - mean;
+            sq2 = __builtin_fmaf(d, d, sq2);
+        }
+        var = group_sum(sq2) * (1.0f / 256.0f);
     }
-    const float ve = group_sum(sq) * (1.0f / 256.0f) + 1e-5f;
+    const float ve = var + 1e-5f;
     float rstd = __builtin_amdgcn_rsqf(ve);
     rstd = rstd * __builtin_fmaf(-0.5f * ve * rstd, rstd, 1.5f);
     const f32x4* gam = (const f32x4*)(small_l + kHidden + g * 64);
@@ -138,7 +149,7 @@ __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const fl
         f32x4 xh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            xh[r] = (act[4 * T + r] - mean) * rstd;
+            xh[r] = __builtin_fmaf(act[4 * T + r], rstd, shift);
             if (kTrain) xh[r] = (act[4 * T + r] > 0.f && xh[r] <= shift) ? above : xh[r];
             act[4 * T + r] = __builtin_fmaf(xh[r], ga[r], be[r]);
         }

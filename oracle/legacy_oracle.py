@@ -137,12 +137,18 @@ def render_rays(params, cfg, rays_o, rays_d, near, far, num_samples, u=None, noi
     n = rays_o.shape[0]
     t = sample_t(n, near, far, num_samples, u)
     points = rays_o[:, None, :] + rays_d[:, None, :] * t[..., None]
-    density, color = field(params, cfg, points, rays_d[:, None, :].expand_as(points), gates, record)
+    density, color = field(params, cfg, points, rays_d[:, None, :].expand_as(points),
+                           None if gates is None else gates[:10], record)
     if noise is not None:
         density = density + noise * density_noise_std
     gaps = points[..., 1:, :] - points[..., :-1, :]
     dists = F.pad(torch.linalg.norm(gaps, dim=-1, keepdim=True), (0, 0, 0, 1), value=1e10)
-    trans = torch.exp(-F.relu(density) * dists)
+    # an ELEVENTH gate: the ReLU of the (noisy) density the compositing runs with — with a noise draw a density can sit
+    # within rounding of zero like any pre-activation (gates[10] forces it, record receives the oracle's own)
+    if record is not None:
+        record.append((density > 0).detach())
+    dens_pos = F.relu(density) if gates is None or len(gates) <= 10 else density * gates[10].to(density.dtype)
+    trans = torch.exp(-dens_pos * dists)
     weights = (1.0 - trans) * F.pad(torch.cumprod(trans[..., :-1, :] + 1e-10, dim=-2), (0, 0, 1, 0), value=1.0)
     rgb = (weights * torch.sigmoid(color)).sum(dim=-2)
     if return_stages:

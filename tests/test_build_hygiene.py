@@ -184,7 +184,7 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
     "nerf_render_fwd_kernelILb0ELb1ELb1ELi16E": (28, 0),
     "nerf_bwd_data_h_kernel": (24, 0),
     "nerf_wgrad_h_kernel": (12, 0),
-    "nerf_legacy_fwd_kernelILb1E": (76, 0),
+    "nerf_legacy_fwd_kernelILb1E": (68, 0),
     "nerf_legacy_fwd_h_kernelILb0E": (60, 0),
     "nerf_legacy_fwd_h_kernelILb1E": (124, 1),
     "nerf_legacy_bwd_data_kernel": (272, 0),

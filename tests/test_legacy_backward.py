@@ -70,15 +70,16 @@ def oracle_gradients(params, loss_fn, dtype):
 
 def kernel_gates(model, n_rays, num_samples):
     """The ten wide layers' ReLU gates [n, S, 256] the training forward of ``model`` just ran with (its saved
-    workspace: ``model.keep_workspace`` must be set)."""
-    return [g.cpu() for g in W.legacy_saved_gates(model.last_workspace, n_rays, num_samples)]
+    workspace: ``model.keep_workspace`` must be set), and the gate of the (noisy) density its compositing ran with."""
+    return [g.cpu() for g in W.legacy_saved_gates(model.last_workspace, n_rays, num_samples)] + \
+        [W.legacy_saved_density_gate(model.last_workspace, n_rays, num_samples)]
 
 
 def check_gates(own, gates):
     """The kernel's gates against the oracle's own: they may only differ where y sits within rounding of zero."""
     flips = sum(int((a != b).sum()) for a, b in zip(own, gates))
     total = sum(a.numel() for a in gates)
-    assert len(own) == len(gates) == 10 and flips <= GATE_FLIP_BOUND * total, (flips, total)
+    assert len(own) == len(gates) == 11 and flips <= GATE_FLIP_BOUND * total, (flips, total)     # ten wide layers + the density
     return flips, total
 
 

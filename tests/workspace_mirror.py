@@ -180,3 +180,11 @@ def legacy_saved_gates(workspace, n_rays, num_samples):
         xhat, _, shift = legacy_saved_layer(workspace, layer, n_rays, num_samples)
         gates.append(xhat > shift[..., None])
     return gates
+
+
+def legacy_saved_density_gate(workspace, n_rays, num_samples):
+    """The ReLU gate of the (noisy) density the legacy compositing ran with: slot 3 of its state [sp][4] = (alpha,
+    T_exclusive, dist, density + noise) > 0; [n, S, 1]."""
+    lay = legacy_train_layout(n_rays, num_samples)
+    comp = _legacy_rows(workspace, lay, lay["comp"], 4, n_rays, num_samples)
+    return (comp[..., 3:4] > 0).cpu()
