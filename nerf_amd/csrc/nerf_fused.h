@@ -142,8 +142,10 @@ __device__ __forceinline__ LazyNorm finish_moments_at(const Mom& m, const f32x4 
         //  into 4 NT compares, which depend on nothing but the lane and the launch and are hoisted to the top of the
         //  kernel as 64 lane masks = 128 scalar registers, parked in vector-register lanes and crowding the values the
         //  hot path needs out with them: 187 v_writelane in the prologue, ~95 v_readlane per 16-sample chunk)
+        // (the legacy network's split-precision kernels, at 256 registers, keep the plain form: with the barrier their
+        //  allocation moves a reload between two layers)
         int lim = nd.real - 4 * g;
-        asm volatile("" : "+v"(lim));
+        if (kOrder != kOrderReluNorm) asm volatile("" : "+v"(lim));
         float v = 0.f;
 #pragma unroll
         for (int T = 0; T < NT; ++T) {

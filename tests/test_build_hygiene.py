@@ -176,12 +176,12 @@ def test_loader_refuses_a_library_older_than_its_sources(tmp_path):
 SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses between two MFMAs)
     # the split-precision render kernel at 8 register tiles runs THREE workgroups per CU (<= 168 registers, no LDS
     # stash): 7 values of the front end / compositing state spill around the MLP, none inside its loops
-    "nerf_render_fwd_kernelILb0ELb1ELb0ELi8E": (28, 0),
+    "nerf_render_fwd_kernelILb0ELb1ELb0ELi8E": (24, 0),
     # the split-precision kernel WITH per-sample outputs (NeRF.forward under no_grad, the hierarchical sampler's coarse
     # pass): since color_outputs is a run-time count its out_raw store computes the column of each slot of output tile 0
     # per lane (nerf_layout.h: row_of_tile0) — three 8-byte addresses hoisted in the front end are parked around the
     # MLP, 8 scratch instructions per ray, none inside a loop.  Not a bench path.
-    "nerf_render_fwd_kernelILb0ELb1ELb1ELi16E": (28, 0),
+    "nerf_render_fwd_kernelILb0ELb1ELb1ELi16E": (20, 0),
     "nerf_bwd_data_h_kernel": (24, 0),
     "nerf_wgrad_h_kernel": (12, 0),
     "nerf_legacy_fwd_kernelILb1E": (68, 0),
