@@ -342,6 +342,67 @@ def test_narrow_networks_vs_the_reference_fixture(tag, kw, precision):
         assert e <= 5e-6 + 8 * floor + 1.5 * moved, (k, e, floor, flips, moved)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_segmentation_of_classes_far_below_the_leading_one(precision):
+    """The compositing sums a class's terms 2^(v - B + 100) with ONE stabiliser B per 16-sample chunk (the largest
+    log2(w + 1e-10): nerf_device.h: composite_chunk) where the reference takes a maximum per class (nerf/model.py:
+    660-663).  Classes whose logits sit 60 and 120 below the leading one — soft-max probabilities of 1e-26 and 1e-52,
+    far below anything fp32 represents relative to 1 — must still come out finite and equal to the oracle's."""
+    dev = torch.device("cuda:0")
+    shape = (7, 256, 32)
+    cfg, params, model = setup(shape, seed=33)
+    bias = params["prediction_heads.15.bias"].clone()
+    bias[4 + 0] += 8.0             # class 0 leads
+    bias[4 + 2] -= 60.0
+    bias[4 + 5] -= 120.0
+    params["prediction_heads.15.bias"] = bias
+    model.load_state_dict(params)
+    model.precision = precision
+    n, S = 64, 40
+    g = torch.Generator().manual_seed(4)
+    o, d = torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0.0, -3.0, 2.6]), torch.randn(n, 3, generator=g)
+    u = torch.rand(n, S, generator=g)
+    with torch.no_grad():
+        p64 = {k: v.double() for k, v in params.items()}
+        _, want = O.render_rays(p64, cfg, o.double(), d.double(), S, u=u.double())
+        ok = O.render_rays(params, cfg, o, d, S, u=u, return_stages=True)[2]["density"][:, -1, 0].abs() > 1e-5   # (SURVEY 0.8)
+        _, got = model.render_rays(o.to(dev), d.to(dev), S, randomly_sample=True, u=u.to(dev))
+    got, want = got[:, 0].cpu().double()[ok], want[ok]
+    assert int(ok.sum()) >= n // 2 and torch.isfinite(got).all()
+    assert float(want[:, 2].max()) < -50 and float(want[:, 5].max()) < -100          # the case is what it says
+    # (log space: 1e-3 absolute on values of -60 ... -140; the logits themselves carry 1e-5 of rounding here)
+    assert float((got - want).abs().max()) <= 1e-3, (got - want).abs().max(dim=0).values
+
+
+def test_the_resident_kernel_with_ragged_ray_counts_and_row_blocks():
+    """hidden_size <= 64 renders through the kernel that keeps its weight image resident in LDS: ONE workgroup of 16
+    waves per CU, a ray per wave (nerf_render.hip: resident_weights).  Ray counts around its 16-ray groups and its
+    4,096-wave grid, and a frame cut into row blocks (nerf_amd/parallel.py), bit for bit against the whole."""
+    dev = torch.device("cuda:0")
+    shape = (7, 64, 16)
+    cfg, params, model = setup(shape, seed=12)
+    g = torch.Generator().manual_seed(8)
+    big = 4096 + 33
+    o = torch.randn(big, 3, generator=g) * 0.3 + torch.tensor([0.0, -3.0, 2.6])
+    d = torch.randn(big, 3, generator=g)
+    S = 20
+    with torch.no_grad():
+        whole_rgb, whole_seg = model.render_rays(o.to(dev), d.to(dev), S)
+        ref_rgb, ref_seg, st = O.render_rays(params, cfg, o[:300], d[:300], S, return_stages=True)
+        ok = st["density"][:, -1, 0].abs() > 1e-5
+        assert (whole_rgb[:300, 0].cpu() - ref_rgb)[ok].abs().max() <= 1e-5
+        for n in (1, 15, 16, 17, 255, 4096, 4097):
+            rgb, seg = model.render_rays(o[:n].to(dev), d[:n].to(dev), S)
+            assert torch.equal(rgb, whole_rgb[:n]) and torch.equal(seg, whole_seg[:n]), n
+        cam_o = torch.tensor([[0.0, -3.0, 2.6]])
+        cam_r = O.look_at_pose([0.0, -3.0, 2.6])
+        img, img_seg = model.render_image(cam_o.to(dev), cam_r.to(dev), 37, 23, 30.0, S)
+        rows = [model.render_image(cam_o.to(dev), cam_r.to(dev), 37, 23, 30.0, S, row_begin=b, row_end=e)
+                for b, e in ((0, 5), (5, 6), (6, 37))]
+        assert torch.equal(torch.cat([r[0] for r in rows], dim=1), img)
+        assert torch.equal(torch.cat([r[1] for r in rows], dim=1), img_seg)
+
+
 def test_shapes_the_kernels_do_not_take_are_refused():
     from nerf_amd import NeRF
     dev = torch.device("cuda:0")
