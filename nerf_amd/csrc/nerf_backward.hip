@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_kernel(const BwdArgs ba)
 // the two-stage layer-5 loop), so they take their turns at the end of the item, a barrier apart.
 // NT = 4 (hidden_size <= 64, round 6: nerf_device.h: train_compute_tiles): the chain COMPUTES at 4 register tiles on
 // the image at kNarrowBwd4Offset (one stage per layer), the rows it reads and writes stay 128 wide — it loads tiles
-// 0 .. 3 of x_hat and writes tiles 4 .. 7 of dY as zeros for the 8-tile weight gradient.  A one-stage loop has one
+// 0 .. 3 of x_hat and writes tiles 0 .. 3 of dY (nerf_wgrad_n4_kernel fetches no others).  A one-stage loop has one
 // barrier, so EVERY layer's gamma / beta partials take their four turns behind explicit barriers, and the next
 // LayerNorm backward's x_hat is fetched at stage 0.
 template <int NT>
@@ -232,12 +232,8 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n_kernel(const BwdArgs b
         }
         turn.kg = turn.kb = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto zero_upper = [&](float* row) {           // NT = 4: tiles 4 .. 7 of a 128-wide saved row
-        if (NT == 4) {
-#pragma unroll
-            for (int T = 4; T < 8; ++T) *(f32x4*)(row + T * kTileT) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
+    // (NT = 4: tiles 4 .. 7 of the 128-wide saved rows are never written — the weight gradient of such a network fetches
+    //  tiles 0 .. 3 only, nerf_wgrad_n4_kernel)
 
     for (int64_t grp = blockIdx.x; grp < ba.groups; grp += gridDim.x) {
         const int64_t tile = grp * kWavesPerWg + wave;      // = slot * chunks + c
@@ -267,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n_kernel(const BwdArgs b
             float* const dyrow = ws + ba.L.dy[L] + tile_lane_base(sp, g, kTileN);
             layer_norm_relu_bwd<false, NT>(small + L * kSmallPerLayerLds, g, j, acc, act, xh, rstd, dyrow, gb + L * 2 * kHidden, turn,
                                            ba.inv_n);
-            zero_upper(dyrow);
             if (NT == 4) take_turns();
 #pragma unroll
             for (int T = 0; T < NT; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -283,7 +278,6 @@ __global__ __launch_bounds__(256, 2) void nerf_bwd_data_n_kernel(const BwdArgs b
         {
             float* const dyrow = ws + ba.L.dy[0] + tile_lane_base(sp, g, kTileN);
             layer_norm_relu_bwd<false, NT>(small, g, j, acc, act, xh, rstd, dyrow, gb, turn, ba.inv_n);
-            zero_upper(dyrow);
         }
         take_turns();                             // layer 0's partials (NT = 8: the only ones without a loop behind them)
     }
@@ -646,6 +640,32 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_n8_kernel(const BwdArgs ba)
     }
 }
 
+// ... and at 4 (hidden_size <= 64, fp32 arithmetic: nerf_device.h: train_compute_tiles): the same shapes and wave maps
+// — three of a hidden job's four waves multiply zeros — on HALF the bytes: the forward and the data gradient wrote
+// register tiles 0..3 of the 128-wide rows only, so only those are fetched (one DMA piece per wave and operand instead
+// of two) and the other tiles' places in the ring slots are zeroed here, once.
+__global__ __launch_bounds__(256, 1) void nerf_wgrad_n4_kernel(const BwdArgs ba) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < kRingSlots * kRingSlotBytes / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
+    const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
+                      ba.data_grid, 8};
+    const float* ws = ba.a.train_workspace;
+    const float* small = ba.a.packed + kBlobFloats;
+    if (job < 4) {
+        wgrad_body_ring<ShapeHidN4, kInputAffineRelu>(jb, smem, ws + ba.L.dy[1] + (int64_t)job * ba.L.mp * 128,
+                                                      ws + ba.L.xhat[0] + (int64_t)job * ba.L.mp * 128,
+                                                      small + job * kSmallPerLayer, kSlabWh + job * kHidden * kHidden,
+                                                      kSlabB + (job + 1) * kHidden);
+    } else if (job == 4) {
+        wgrad_body_ring<ShapeL0N4, kInputRaw>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
+    } else {
+        wgrad_body_ring<ShapeL5N4, kInputAffineRelu>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,
+                                                     kSlabW5, kSlabB + 5 * kHidden);
+    }
+}
+
 // The same launch in the split-precision training mode (f16-pair operands, see wgrad_body_ring).
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_h_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -828,10 +848,12 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_h_kernel, kRingSlots * kRingSlotBytes, device,
                                          &done_wgrad_h);
     if (rc) return rc;
-    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0, done_data_h_n8 = 0, done_wgrad_h_n8 = 0, done_data_n4 = 0;
+    static unsigned done_data_n8 = 0, done_wgrad_n8 = 0, done_data_h_n8 = 0, done_wgrad_h_n8 = 0, done_data_n4 = 0, done_wgrad_n4 = 0;
     const int ct = train_compute_tiles(shape_of(a).hidden, half);     // 4: hidden_size <= 64 in fp32 arithmetic
     if (ct == 4) {
         rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n_kernel<4>, kBwdLdsBytes, device, &done_data_n4);
+        if (rc) return rc;
+        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n4_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n4);
         if (rc) return rc;
     }
     if (tt == 8) {
@@ -869,6 +891,8 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         nerf_common::TimedLaunch timed(st, NERF_HIP_TIMING_WEIGHT_GRADIENT);
         if (tt == 8 && wgrad_half)
             hipLaunchKernelGGL(nerf_wgrad_h_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+        else if (ct == 4)
+            hipLaunchKernelGGL(nerf_wgrad_n4_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
         else if (tt == 8)
             hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
         else if (wgrad_half)

@@ -335,9 +335,13 @@ constexpr int kKs = 32;                          // samples per LDS tile
 //   kMapGrid: 2 x 2 waves of TO x TI tiles each;  kMapRows: wave w takes out tiles TO w .. TO w + TO - 1 and
 //   all TI in tiles;  kMapCols: all TO out tiles, in tiles TI w .. TI w + TI - 1
 constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2;
-template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W>
+// HALF: of a TILED operand (128-wide saved rows) only register tiles 0..3 of every 16-sample block are fetched — a
+// network of hidden_size <= 64 that computes its forward and data gradient at 4 tiles never writes the others; their
+// places in the ring slots are zeroed once, at the top of the kernel (nerf_backward.hip: nerf_wgrad_n4_kernel).
+template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false>
 struct WgradShape {
     static constexpr int kMap = MAP;
+    static constexpr bool kHalf = HALF;
     static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
     static constexpr int kSlabStride = SLAB_STRIDE;            // floats between two rows of the product in the partial slab
     static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
@@ -358,6 +362,10 @@ typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden> ShapeL5N8; // waves: b
 // ring slot and write rows 128..255 of the full-width slab, which the reduce kernel never reads for such a network
 // (an odd out-tile count per wave is not an option: the A operand sets ping-pong slot by slot).
 typedef WgradShape<128, kEncIn, 2, 3, kMapRows> ShapeL0N8;
+// ... and at 4 (hidden_size <= 64, fp32 arithmetic): the 8-tile shapes and wave maps on HALF the bytes
+typedef WgradShape<128, 128, 2, 2, kMapGrid, kHidden, true> ShapeHidN4;
+typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true> ShapeL5N4;
+typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true> ShapeL0N4;
 
 // ---------------------------------------------------------------------------------------------
 // The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
@@ -468,8 +476,9 @@ constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 
 // N (<= 4) consecutive 1 KiB pieces, the first an EVEN one: global (uniform base + k KiB + this lane's 16 bytes)
 // -> LDS (base + k KiB + lane * 16).  kTiled: LDS chunk `lane` = (s & 3, s >> 2, g) takes the tile's chunk (g, s) —
 // of sample s ^ 4 in odd pieces.
+// (first_odd: the first piece is an odd one — wave-uniform; only the half-fetch shapes issue single pieces)
 template <int N, bool kTiled>
-__device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
+__device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane, int first_odd = 0) {
     static_assert(N >= 1 && N <= 4, "immediate offsets reach 3 KiB");
     const uint64_t base_u = (uint64_t)(uintptr_t)src;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
@@ -477,8 +486,9 @@ __device__ __forceinline__ void ring_dma(const char* src, char* dst, int lane) {
     const uint64_t sbase = ((uint64_t)hi << 32) | lo;
     const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
     const int sample = 4 * ((lane >> 2) & 3) + (lane >> 4);               // of LDS chunk `lane`
-    const int chunk_even = kTiled ? (lane & 3) * 16 + sample : lane;
-    const int chunk_odd = kTiled ? chunk_even ^ 4 : lane;
+    const int chunk_first = kTiled ? (lane & 3) * 16 + sample : lane;
+    const int chunk_even = kTiled ? chunk_first ^ (first_odd << 2) : lane;      // (of this call's pieces 0, 2)
+    const int chunk_odd = kTiled ? chunk_even ^ 4 : lane;                        // (pieces 1, 3)
     uint32_t m0_saved;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -503,12 +513,15 @@ struct RingPlan {
     typedef SlotLayout<Sh::kInW> X;
     static constexpr int kDyPieces = Dy::kPieces;                         // 16 / 16 / 4
     static constexpr int kXPieces = X::kPieces;                           // 6 / 16 / 16
-    static constexpr int kDyPerWave = (kDyPieces + 3) / 4, kXPerWave = (kXPieces + 3) / 4;
+    // pieces FETCHED per k-step (WgradShape: HALF): the first half of a tiled operand's
+    static constexpr int kDyFetch = Dy::kTiled && Sh::kHalf ? kDyPieces / 2 : kDyPieces;
+    static constexpr int kXFetch = X::kTiled && Sh::kHalf ? kXPieces / 2 : kXPieces;
+    static constexpr int kDyPerWave = (kDyFetch + 3) / 4, kXPerWave = (kXFetch + 3) / 4;
     static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
     static constexpr int kXOffset = Dy::kBytes;                           // X behind dY in the slot
     static_assert(Dy::kBytes + X::kBytes <= kRingSlotBytes, "a k-step must fit its slot");
-    static_assert((!Dy::kTiled || kDyPieces % 4 == 0) && (!X::kTiled || kXPieces % 4 == 0),
-                  "a wave's share of a tiled operand starts at an even tile");
+    static_assert((!Dy::kTiled || kDyFetch % 4 == 0) && (!X::kTiled || kXFetch % 4 == 0),
+                  "the waves' shares of a tiled operand are whole and equal");
 };
 
 // part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
@@ -517,15 +530,15 @@ template <class Sh, int kPart>
 __device__ __forceinline__ void ring_issue_part(const float* dy, const float* x, int64_t sample0, char* slot,
                                                 int wave, int lane) {
     typedef RingPlan<Sh> P;
-    constexpr int total = kPart == 0 ? P::kDyPieces : P::kXPieces;
+    constexpr int total = kPart == 0 ? P::kDyFetch : P::kXFetch;
     constexpr int per = kPart == 0 ? P::kDyPerWave : P::kXPerWave;
     int first = wave * per;
     if (first + per > total) first = total - per;
     const char* src = kPart == 0 ? (const char*)(dy + sample0 * Sh::kOutW) : (const char*)(x + sample0 * Sh::kInW);
     char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
     constexpr bool tiled = kPart == 0 ? P::Dy::kTiled : P::X::kTiled;
-    static_assert(!tiled || per % 2 == 0, "first piece of a wave even");
-    ring_dma<per, tiled>(src + first * 1024, dst + first * 1024, lane);
+    static_assert(!tiled || per % 2 == 0 || per == 1, "first piece of a wave even, or single pieces");
+    ring_dma<per, tiled>(src + first * 1024, dst + first * 1024, lane, tiled && per == 1 ? first & 1 : 0);
 }
 
 struct H2 {                   // an operand as f16 pairs: value = (h + l) / scale

@@ -95,8 +95,9 @@ __host__ __device__ inline TrainLayout make_train_layout(int64_t n_rays, int chu
 // <= 64 trains at 8 too — the weight gradient's 2 x 2 wave grid needs 4 x 4 accumulator tiles), else 16
 __host__ __device__ inline int train_tiles(int hidden) { return hidden <= 128 ? 8 : 16; }      // (both arithmetics)
 // ... and the register tiles the training forward and the data gradient COMPUTE at: 4 for hidden_size <= 64 in fp32
-// arithmetic (a quarter of the MFMAs; tiles 4 .. 7 of the 128-wide saved rows are written as zeros for the weight
-// gradient, whose products with them land in rows / columns the reduce kernel never copies), else train_tiles
+// arithmetic (a quarter of the MFMAs; tiles 4 .. 7 of the 128-wide saved rows are left unwritten: the weight gradient
+// of such a network fetches tiles 0 .. 3 only and multiplies the others' places, zeroed once, in its ring slots —
+// nerf_backward.hip: nerf_wgrad_n4_kernel), else train_tiles
 __host__ __device__ inline int train_compute_tiles(int hidden, bool half) { return !half && hidden <= 64 ? 4 : train_tiles(hidden); }
 
 // Saved 256-wide rows (x_hat of every hidden layer, dY of every layer; both networks) are TILE-MAJOR: the

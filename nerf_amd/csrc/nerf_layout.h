@@ -126,7 +126,7 @@ constexpr int kNarrowH8Offset = kNarrowBwd8Offset + kNarrowBwd8Stages * kStageFl
 constexpr int kNarrowBwdH8Stages = 2 + 4 * 4;
 constexpr int kNarrowBwdH8Offset = kNarrowH8Offset + kNarrowH8Stages * kStageFloats;
 // ... and the transposed fp32 image at 4 register tiles (hidden_size <= 64 training in fp32 arithmetic: forward and
-// data gradient COMPUTE at 4 tiles, the saved rows stay 128 wide for the 8-tile weight gradient): quads numbered
+// data gradient COMPUTE at 4 tiles, the saved rows stay 128 wide, their tiles 4 .. 7 unused): quads numbered
 // k-group * 4 + in tile: layer 5 = 4 k-groups of padded outputs x 4 in tiles = 1 stage, layers 4, 3, 2, 1 = 4 k-groups
 // x 4 in tiles = 1 stage each
 constexpr int kNarrowBwd4Stages = 1 + 4;

@@ -371,8 +371,8 @@ __global__ __launch_bounds__((resident_weights<kTrain, kHalf, kPerSample, NT>() 
 void nerf_render_fwd_kernel(const KernelArgs ka) {
     static_assert(!(kTrain && kPerSample), "the training forward has no per-sample outputs");
     static_assert(NT != 4 || !kHalf, "4 register tiles: fp32 arithmetic only (the split-precision arithmetic runs at 8 or 16)");
-    // saved x_hat rows of a training forward: 128 wide for the narrow networks at EITHER compute width (the weight
-    // gradient runs at 8 register tiles): a 4-tile forward writes tiles 4 .. 7 as zeros
+    // saved x_hat rows of a training forward: 128 wide for the narrow networks at EITHER compute width; a 4-tile forward
+    // leaves tiles 4 .. 7 unwritten (its data and weight gradient read tiles 0 .. 3 only: nerf_wgrad_n4_kernel)
     constexpr int kSaveTiles = NT == 4 ? 8 : NT;
     typedef Narrow<NT> N;
     constexpr bool kResident = resident_weights<kTrain, kHalf, kPerSample, NT>();
@@ -471,12 +471,6 @@ void nerf_render_fwd_kernel(const KernelArgs ka) {
                 for (int t = 0; t < kStagesL0; ++t) *(f32x4*)(hrow + 16 * t) = X[t];
             }
             float* const xrow = kTrain ? ws + tile_lane_base(sp, g, 256 * kSaveTiles) : nullptr;     // + ka.save.xhat[L] (tile-major)
-            if (kTrain && NT == 4) {
-#pragma unroll
-                for (int L = 0; L < 5; ++L)
-#pragma unroll
-                    for (int T = 4; T < 8; ++T) *(f32x4*)(xrow + ka.save.xhat[L] + T * kTileT) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
             float* const rstd_p = kTrain ? ws + sp : nullptr;                      // + ka.save.rstd[L]
 
             LazyNorm norm;
