@@ -644,9 +644,9 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_n8_kernel(const BwdArgs ba)
 // — three of a hidden job's four waves multiply zeros — on HALF the bytes: the forward and the data gradient wrote
 // register tiles 0..3 of the 128-wide rows only, so only those are fetched (one DMA piece per wave and operand instead
 // of two) and the other tiles' places in the ring slots are zeroed here, once.
-__global__ __launch_bounds__(256, 1) void nerf_wgrad_n4_kernel(const BwdArgs ba) {
+__global__ __launch_bounds__(256, 2) void nerf_wgrad_n4_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int i = threadIdx.x; i < kRingSlots * kRingSlotBytes / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < kRingSlots * kRingSlotBytesNarrow / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
     const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
@@ -853,7 +853,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
     if (ct == 4) {
         rc = nerf_common::ensure_dynamic_lds((const void*)nerf_bwd_data_n_kernel<4>, kBwdLdsBytes, device, &done_data_n4);
         if (rc) return rc;
-        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n4_kernel, kRingSlots * kRingSlotBytes, device, &done_wgrad_n4);
+        rc = nerf_common::ensure_dynamic_lds((const void*)nerf_wgrad_n4_kernel, kRingSlots * kRingSlotBytesNarrow, device, &done_wgrad_n4);
         if (rc) return rc;
     }
     if (tt == 8) {
@@ -892,7 +892,7 @@ int nerf_hip_render_backward(const NerfHipBackwardArgs* args, void* stream) {
         if (tt == 8 && wgrad_half)
             hipLaunchKernelGGL(nerf_wgrad_h_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
         else if (ct == 4)
-            hipLaunchKernelGGL(nerf_wgrad_n4_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
+            hipLaunchKernelGGL(nerf_wgrad_n4_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytesNarrow, st, ba);
         else if (tt == 8)
             hipLaunchKernelGGL(nerf_wgrad_n8_kernel, dim3(ba.splits * wgrad_jobs), dim3(256), kRingSlots * kRingSlotBytes, st, ba);
         else if (wgrad_half)

@@ -338,10 +338,15 @@ constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2;
 // HALF: of a TILED operand (128-wide saved rows) only register tiles 0..3 of every 16-sample block are fetched — a
 // network of hidden_size <= 64 that computes its forward and data gradient at 4 tiles never writes the others; their
 // places in the ring slots are zeroed once, at the top of the kernel (nerf_backward.hip: nerf_wgrad_n4_kernel).
-template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false>
+// SLOT_KIB: bytes of a ring slot of the kernel the shape runs in (all shapes of one kernel share it): 32 KiB, one
+// workgroup per CU; 16 KiB for the half-fetch shapes — a 64 KiB ring, TWO workgroups per CU (measured on one box:
+// the 4-tile weight gradient 0.330 -> 0.270 ms; the 8-tile ones with the same change 0.366 -> 0.362 ms in fp32 and
+// 0.321 -> 0.333 ms on f16 pairs, so they keep the one-workgroup form).
+template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false, int SLOT_KIB = 32>
 struct WgradShape {
     static constexpr int kMap = MAP;
     static constexpr bool kHalf = HALF;
+    static constexpr int kSlotBytes = SLOT_KIB * 1024;
     static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
     static constexpr int kSlabStride = SLAB_STRIDE;            // floats between two rows of the product in the partial slab
     static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
@@ -363,9 +368,9 @@ typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden> ShapeL5N8; // waves: b
 // (an odd out-tile count per wave is not an option: the A operand sets ping-pong slot by slot).
 typedef WgradShape<128, kEncIn, 2, 3, kMapRows> ShapeL0N8;
 // ... and at 4 (hidden_size <= 64, fp32 arithmetic): the 8-tile shapes and wave maps on HALF the bytes
-typedef WgradShape<128, 128, 2, 2, kMapGrid, kHidden, true> ShapeHidN4;
-typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true> ShapeL5N4;
-typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true> ShapeL0N4;
+typedef WgradShape<128, 128, 2, 2, kMapGrid, kHidden, true, 16> ShapeHidN4;
+typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true, 16> ShapeL5N4;
+typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true, 16> ShapeL0N4;
 
 // ---------------------------------------------------------------------------------------------
 // The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
@@ -472,6 +477,7 @@ __device__ __forceinline__ OperandRows operand_rows(const char* region, int kk, 
     return OperandRows{{r + L::lane(kk, i, 0), r + L::lane(kk, i, 1)}};
 }
 constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 KiB (hidden shape)
+constexpr int kRingSlotBytesNarrow = kRingStep * (128 + 128) * 4;         // 16 KiB (128-wide rows: WgradShape SLOT_KIB)
 
 // N (<= 4) consecutive 1 KiB pieces, the first an EVEN one: global (uniform base + k KiB + this lane's 16 bytes)
 // -> LDS (base + k KiB + lane * 16).  kTiled: LDS chunk `lane` = (s & 3, s >> 2, g) takes the tile's chunk (g, s) —
@@ -519,7 +525,7 @@ struct RingPlan {
     static constexpr int kDyPerWave = (kDyFetch + 3) / 4, kXPerWave = (kXFetch + 3) / 4;
     static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
     static constexpr int kXOffset = Dy::kBytes;                           // X behind dY in the slot
-    static_assert(Dy::kBytes + X::kBytes <= kRingSlotBytes, "a k-step must fit its slot");
+    static_assert(Dy::kBytes + X::kBytes <= Sh::kSlotBytes, "a k-step must fit its slot");
     static_assert((!Dy::kTiled || kDyFetch % 4 == 0) && (!X::kTiled || kXFetch % 4 == 0),
                   "the waves' shares of a tiled operand are whole and equal");
 };
@@ -644,7 +650,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     const int64_t sample_begin = tile_begin * kKs;
     const int i = lane & 31, kk = lane >> 5;
 
-    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * kRingSlotBytes; };
+    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * Sh::kSlotBytes; };
     auto issue_step = [&](int64_t t) {            // all pieces of step t (prologue)
         ring_issue_part<Sh, 0>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
         ring_issue_part<Sh, 1>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
