@@ -334,14 +334,17 @@ constexpr int kKs = 32;                          // samples per LDS tile
 // kMap: how the four waves split the [OUT_W x IN_W] product into 32 x 32 accumulator tiles
 //   kMapGrid: 2 x 2 waves of TO x TI tiles each;  kMapRows: wave w takes out tiles TO w .. TO w + TO - 1 and
 //   all TI in tiles;  kMapCols: all TO out tiles, in tiles TI w .. TI w + TI - 1
-constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2;
+//   kMapPrivate: every wave the WHOLE TO x TI block of its OWN job — the caller hands each wave its own dY / X /
+//   slab offsets (the four hidden layers of a network of hidden_size <= 64: one 2 x 2 block each), the wave fetches
+//   its own operands into its own part of the ring slot and shares nothing with the others but the barriers
+constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2, kMapPrivate = 3;
 // HALF: of a TILED operand (128-wide saved rows) only register tiles 0..3 of every 16-sample block are fetched — a
 // network of hidden_size <= 64 that computes its forward and data gradient at 4 tiles never writes the others; their
 // places in the ring slots are zeroed once, at the top of the kernel (nerf_backward.hip: nerf_wgrad_n4_kernel).
 // SLOT_KIB: bytes of a ring slot of the kernel the shape runs in (all shapes of one kernel share it): 32 KiB, one
-// workgroup per CU; 16 KiB for the half-fetch shapes — a 64 KiB ring, TWO workgroups per CU (measured on one box:
-// the 4-tile weight gradient 0.330 -> 0.270 ms; the 8-tile ones with the same change 0.366 -> 0.362 ms in fp32 and
-// 0.321 -> 0.333 ms on f16 pairs, so they keep the one-workgroup form).
+// workgroup per CU.  (16 KiB slots — a 64 KiB ring, TWO workgroups per CU — were measured on the kernels that read
+// 128-wide rows: the half-fetch 4-tile form 0.330 -> 0.270 ms, the 8-tile ones 0.366 -> 0.362 ms in fp32 and 0.321 ->
+// 0.333 ms on f16 pairs; the 4-tile kernel then took the per-layer wave map below, which needs the 32 KiB.)
 template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false, int SLOT_KIB = 32>
 struct WgradShape {
     static constexpr int kMap = MAP;
@@ -368,9 +371,9 @@ typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden> ShapeL5N8; // waves: b
 // (an odd out-tile count per wave is not an option: the A operand sets ping-pong slot by slot).
 typedef WgradShape<128, kEncIn, 2, 3, kMapRows> ShapeL0N8;
 // ... and at 4 (hidden_size <= 64, fp32 arithmetic): the 8-tile shapes and wave maps on HALF the bytes
-typedef WgradShape<128, 128, 2, 2, kMapGrid, kHidden, true, 16> ShapeHidN4;
-typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true, 16> ShapeL5N4;
-typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true, 16> ShapeL0N4;
+typedef WgradShape<128, 128, 2, 2, kMapPrivate, kHidden, true> ShapeHidN4;       // wave w: hidden layer w + 1
+typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true> ShapeL5N4;
+typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true> ShapeL0N4;
 
 // ---------------------------------------------------------------------------------------------
 // The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
@@ -477,7 +480,6 @@ __device__ __forceinline__ OperandRows operand_rows(const char* region, int kk, 
     return OperandRows{{r + L::lane(kk, i, 0), r + L::lane(kk, i, 1)}};
 }
 constexpr int kRingSlotBytes = kRingStep * (kHidden + kHidden) * 4;       // 32 KiB (hidden shape)
-constexpr int kRingSlotBytesNarrow = kRingStep * (128 + 128) * 4;         // 16 KiB (128-wide rows: WgradShape SLOT_KIB)
 
 // N (<= 4) consecutive 1 KiB pieces, the first an EVEN one: global (uniform base + k KiB + this lane's 16 bytes)
 // -> LDS (base + k KiB + lane * 16).  kTiled: LDS chunk `lane` = (s & 3, s >> 2, g) takes the tile's chunk (g, s) —
@@ -522,12 +524,15 @@ struct RingPlan {
     // pieces FETCHED per k-step (WgradShape: HALF): the first half of a tiled operand's
     static constexpr int kDyFetch = Dy::kTiled && Sh::kHalf ? kDyPieces / 2 : kDyPieces;
     static constexpr int kXFetch = X::kTiled && Sh::kHalf ? kXPieces / 2 : kXPieces;
-    static constexpr int kDyPerWave = (kDyFetch + 3) / 4, kXPerWave = (kXFetch + 3) / 4;
+    static constexpr bool kPrivate = Sh::kMap == kMapPrivate;
+    static constexpr int kDyPerWave = kPrivate ? kDyFetch : (kDyFetch + 3) / 4, kXPerWave = kPrivate ? kXFetch : (kXFetch + 3) / 4;
+    static constexpr int kWaveBytes = kPrivate ? (kDyFetch + kXFetch) * 1024 : 0;      // a wave's own part of a slot
     static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
-    static constexpr int kXOffset = Dy::kBytes;                           // X behind dY in the slot
-    static_assert(Dy::kBytes + X::kBytes <= Sh::kSlotBytes, "a k-step must fit its slot");
+    static constexpr int kXOffset = kPrivate ? kDyFetch * 1024 : Dy::kBytes;       // X behind dY in the slot (or the wave's part)
+    static_assert(kPrivate ? 4 * kWaveBytes <= Sh::kSlotBytes : Dy::kBytes + X::kBytes <= Sh::kSlotBytes, "a k-step must fit its slot");
     static_assert((!Dy::kTiled || kDyFetch % 4 == 0) && (!X::kTiled || kXFetch % 4 == 0),
                   "the waves' shares of a tiled operand are whole and equal");
+    static_assert(!kPrivate || (kDyPerWave <= 4 && kXPerWave <= 4 && Dy::kTiled && X::kTiled), "one DMA call per operand");
 };
 
 // part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
@@ -538,7 +543,7 @@ __device__ __forceinline__ void ring_issue_part(const float* dy, const float* x,
     typedef RingPlan<Sh> P;
     constexpr int total = kPart == 0 ? P::kDyFetch : P::kXFetch;
     constexpr int per = kPart == 0 ? P::kDyPerWave : P::kXPerWave;
-    int first = wave * per;
+    int first = P::kPrivate ? 0 : wave * per;
     if (first + per > total) first = total - per;
     const char* src = kPart == 0 ? (const char*)(dy + sample0 * Sh::kOutW) : (const char*)(x + sample0 * Sh::kInW);
     char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
@@ -601,6 +606,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     int out0, in0;                                // first 32-wide tile of this wave
     if (Sh::kMap == kMapGrid) { out0 = Sh::kTo * (wave >> 1); in0 = Sh::kTi * (wave & 1); }
     else if (Sh::kMap == kMapRows) { out0 = Sh::kTo * wave; in0 = 0; }
+    else if (Sh::kMap == kMapPrivate) { out0 = 0; in0 = 0; }
     else { out0 = 0; in0 = Sh::kTi * wave; }
 
     float ga[Sh::kTi], be[Sh::kTi];
@@ -650,7 +656,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     const int64_t sample_begin = tile_begin * kKs;
     const int i = lane & 31, kk = lane >> 5;
 
-    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * Sh::kSlotBytes; };
+    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * Sh::kSlotBytes + wave * P::kWaveBytes; };
     auto issue_step = [&](int64_t t) {            // all pieces of step t (prologue)
         ring_issue_part<Sh, 0>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
         ring_issue_part<Sh, 1>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
