@@ -113,11 +113,30 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
             scatter_level4(w0, w1, x);
             scatter_take(x, t, j, kept);
         }
+    } else if constexpr (!kScaled && NT == 16) {
+        // fp32 chain: HALF the butterfly — tiles T and T + 8 through scatter_level8 (lanes 0-7 then hold the pair sums of
+        // tile T's eight values, lanes 8-15 of tile T + 8's), then an all-reduce inside each half row: 16 + 24 DPP adds
+        // and 8 selects per tile pair where two tiles of row sums take 64 + 16, with 8 more values live (the full
+        // butterfly, 32 more, costs this kernel 120 - 148 B of spills and was measured slower twice).  Data gradient
+        // 1.278 -> 1.248 ms, step 3.38 -> 3.35 ms (same-box A/B).  (The legacy network's fp32 chain keeps the full
+        // butterfly: with this form its allocation goes from 272 to 524 B of scratch.)
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            float va[8], vb[8], w[8];
+            tile(T, va);
+            tile(T + 8, vb);
+            scatter_level8(va, vb, w);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float x = w[i];
+                x += dpp<kQuadXor1>(0.f, x);
+                x += dpp<kQuadXor2>(0.f, x);
+                x += dpp<kRowHalfMirror>(0.f, x);
+                if ((j & 7) == T) kept[i] = x;
+            }
+        }
     } else {
-        // fp32 chain (matrix-paced: its MFMAs take four times as long): one row_sum per value; the butterfly's
-        // longer live ranges cost this kernel 120 B more spills than its shorter VALU phase gains
-        // (3.88 against 3.81 ms per 4096 x 64 step).  Also the narrow (NT = 8) split-precision chain: the butterfly
-        // is built for sixteen tiles.
+        // the narrow chains (NT = 8 / 4: the butterflies are built for sixteen tiles): one row_sum per value
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
             float v[8];
