@@ -154,12 +154,15 @@ __device__ __forceinline__ void layer_norm_relu_bwd(const float* small_l, int g,
     turn.kb = keep_b;
     const float m1 = group_sum(s1) * inv_n;
     const float m2 = group_sum(s2) * inv_n;
+    // dy = rstd ((gamma dz - m1) - x_hat m2) as two FMAs per element on the per-sample products (three instructions
+    // as written; every VALU instruction of the fp32 chain is kernel time: NOTES.md section R6d)
+    const float c1 = -(rstd * m1), c2 = rstd * m2;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
         f32x4 dy;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            dy[r] = rstd * ((acc[T][r] - m1) - xh[T][r] * m2);
+            dy[r] = __builtin_fmaf(-xh[T][r], c2, __builtin_fmaf(acc[T][r], rstd, c1));
             act[4 * T + r] = dy[r];
         }
         // (kUniformRow: dy_row is the wave's uniform tile base, the lane's offset is taken per store)

@@ -182,7 +182,7 @@ SCRATCH_BUDGET = {            # kernel name fragment: (bytes per lane, accesses 
     # per lane (nerf_layout.h: row_of_tile0) — three 8-byte addresses hoisted in the front end are parked around the
     # MLP, 8 scratch instructions per ray, none inside a loop.  Not a bench path.
     "nerf_render_fwd_kernelILb0ELb1ELb1ELi16E": (20, 0),
-    "nerf_bwd_data_h_kernel": (24, 0),
+    "nerf_bwd_data_h_kernel": (8, 0),
     "nerf_wgrad_h_kernel": (12, 0),
     "nerf_legacy_fwd_kernelILb1E": (68, 0),
     "nerf_legacy_fwd_h_kernelILb0E": (60, 0),
