@@ -643,26 +643,24 @@ __global__ __launch_bounds__(256, 1) void nerf_wgrad_n8_kernel(const BwdArgs ba)
 // ... and at 4 (hidden_size <= 64, fp32 arithmetic: nerf_device.h: train_compute_tiles).  The forward and the data gradient
 // wrote register tiles 0..3 of the 128-wide rows only, so only those are fetched (WgradShape: HALF).  A hidden layer is
 // ONE 2 x 2 block of 32 x 32 accumulator tiles — a wave's worth — so the four hidden layers are one job in which wave w
-// takes layer w + 1 on the same samples (kMapPrivate: its own operands in its own quarter of the ring slot): three jobs
-// of S k-steps instead of six.  Layers 0 and 5 keep the 8-tile wave maps (their other waves multiply the zeros this
-// kernel writes, once, into the unfetched tiles' places of the ring slots).
-constexpr int kWgradJobsN4 = 3;
+// takes layer w + 1 on the same samples (kMapPrivate: its own operands in its own quarter of the ring slot), and
+// layers 0 and 5 are a second job of the same kind — even waves layer 0, odd waves layer 5 (kMapPrivatePair) —: two jobs
+// of S k-steps instead of six.
+constexpr int kWgradJobsN4 = 2;
 __global__ __launch_bounds__(256, 1) void nerf_wgrad_n4_kernel(const BwdArgs ba) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int i = threadIdx.x; i < kRingSlots * kRingSlotBytes / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
     const int job = blockIdx.x / ba.splits, split = blockIdx.x % ba.splits;
     const WgradJob jb{ba.tiles_per_split, ba.n_tiles, split, ba.slabs + (int64_t)split * kSlabFloats, ba.dymax,
                       ba.data_grid, 8};
     const float* ws = ba.a.train_workspace;
     const float* small = ba.a.packed + kBlobFloats;
-    if (job == 0) {
-        const int layer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // hidden layer layer + 1: this wave's
+    const int layer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (job == 0) {                                                                // hidden layer layer + 1: this wave's
         wgrad_body_ring<ShapeHidN4, kInputAffineRelu>(jb, smem, ws + ba.L.dy[1] + (int64_t)layer * ba.L.mp * 128,
                                                       ws + ba.L.xhat[0] + (int64_t)layer * ba.L.mp * 128,
                                                       small + layer * kSmallPerLayer, kSlabWh + layer * kHidden * kHidden,
                                                       kSlabB + (layer + 1) * kHidden);
-    } else if (job == 1) {
+    } else if ((layer & 1) == 0) {
         wgrad_body_ring<ShapeL0N4, kInputRaw>(jb, smem, ws + ba.L.dy[0], ws + ba.L.h, nullptr, kSlabW0, kSlabB);
     } else {
         wgrad_body_ring<ShapeL5N4, kInputAffineRelu>(jb, smem, ws + ba.L.dy5, ws + ba.L.xhat[4], small + 4 * kSmallPerLayer,

@@ -359,7 +359,9 @@ constexpr int kKs = 32;                          // samples per LDS tile
 //   kMapPrivate: every wave the WHOLE TO x TI block of its OWN job — the caller hands each wave its own dY / X /
 //   slab offsets (the four hidden layers of a network of hidden_size <= 64: one 2 x 2 block each), the wave fetches
 //   its own operands into its own part of the ring slot and shares nothing with the others but the barriers
-constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2, kMapPrivate = 3;
+//   kMapPrivatePair: the same with TWO jobs in the workgroup — the even waves run one shape, the odd waves another (the
+//   caller branches on wave & 1), waves 2 and 3 repeat waves 0 and 1 to the same places (same bytes, same results)
+constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2, kMapPrivate = 3, kMapPrivatePair = 4;
 // HALF: of a TILED operand (128-wide saved rows) only register tiles 0..3 of every 16-sample block are fetched — a
 // network of hidden_size <= 64 that computes its forward and data gradient at 4 tiles never writes the others; their
 // places in the ring slots are zeroed once, at the top of the kernel (nerf_backward.hip: nerf_wgrad_n4_kernel).
@@ -367,11 +369,14 @@ constexpr int kMapGrid = 0, kMapRows = 1, kMapCols = 2, kMapPrivate = 3;
 // workgroup per CU.  (16 KiB slots — a 64 KiB ring, TWO workgroups per CU — were measured on the kernels that read
 // 128-wide rows: the half-fetch 4-tile form 0.330 -> 0.270 ms, the 8-tile ones 0.366 -> 0.362 ms in fp32 and 0.321 ->
 // 0.333 ms on f16 pairs; the 4-tile kernel then took the per-layer wave map below, which needs the 32 KiB.)
-template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false, int SLOT_KIB = 32>
+// REGION_KIB (kMapPrivatePair): bytes of a wave's own part of a ring slot — the larger of the two shapes' needs.
+template <int OUT_W, int IN_W, int TO, int TI, int MAP, int SLAB_STRIDE = IN_W, bool HALF = false, int SLOT_KIB = 32,
+          int REGION_KIB = 0>
 struct WgradShape {
     static constexpr int kMap = MAP;
     static constexpr bool kHalf = HALF;
     static constexpr int kSlotBytes = SLOT_KIB * 1024;
+    static constexpr int kRegionBytes = REGION_KIB * 1024;
     static constexpr int kOutW = OUT_W, kInW = IN_W, kTo = TO, kTi = TI;
     static constexpr int kSlabStride = SLAB_STRIDE;            // floats between two rows of the product in the partial slab
     static constexpr int kDyBytes = kKs * OUT_W * 4, kXBytes = kKs * IN_W * 4;
@@ -394,8 +399,9 @@ typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden> ShapeL5N8; // waves: b
 typedef WgradShape<128, kEncIn, 2, 3, kMapRows> ShapeL0N8;
 // ... and at 4 (hidden_size <= 64, fp32 arithmetic): the 8-tile shapes and wave maps on HALF the bytes
 typedef WgradShape<128, 128, 2, 2, kMapPrivate, kHidden, true> ShapeHidN4;       // wave w: hidden layer w + 1
-typedef WgradShape<kOutPad, 128, 2, 1, kMapCols, kHidden, true> ShapeL5N4;
-typedef WgradShape<128, kEncIn, 2, 3, kMapRows, kEncIn, true> ShapeL0N4;
+// layers 0 and 5 as ONE job: the even waves take layer 0 (64 x 96: 2 x 3 tiles), the odd ones layer 5 (64 x 64: 2 x 2)
+typedef WgradShape<kOutPad, 128, 2, 2, kMapPrivatePair, kHidden, true, 32, 10> ShapeL5N4;
+typedef WgradShape<128, kEncIn, 2, 3, kMapPrivatePair, kEncIn, true, 32, 10> ShapeL0N4;
 
 // ---------------------------------------------------------------------------------------------
 // The GEMM with every fp32 operand as a bf16 TRIPLE (hi + mid + lo = all 24 significand
@@ -546,15 +552,18 @@ struct RingPlan {
     // pieces FETCHED per k-step (WgradShape: HALF): the first half of a tiled operand's
     static constexpr int kDyFetch = Dy::kTiled && Sh::kHalf ? kDyPieces / 2 : kDyPieces;
     static constexpr int kXFetch = X::kTiled && Sh::kHalf ? kXPieces / 2 : kXPieces;
-    static constexpr bool kPrivate = Sh::kMap == kMapPrivate;
+    static constexpr bool kPair = Sh::kMap == kMapPrivatePair;
+    static constexpr bool kPrivate = Sh::kMap == kMapPrivate || kPair;
     static constexpr int kDyPerWave = kPrivate ? kDyFetch : (kDyFetch + 3) / 4, kXPerWave = kPrivate ? kXFetch : (kXFetch + 3) / 4;
-    static constexpr int kWaveBytes = kPrivate ? (kDyFetch + kXFetch) * 1024 : 0;      // a wave's own part of a slot
+    // a wave's own part of a slot
+    static constexpr int kWaveBytes = !kPrivate ? 0 : (Sh::kRegionBytes ? Sh::kRegionBytes : (kDyFetch + kXFetch) * 1024);
     static constexpr int kPerWave = kDyPerWave + kXPerWave;               // 6 / 8 / 5
     static constexpr int kXOffset = kPrivate ? kDyFetch * 1024 : Dy::kBytes;       // X behind dY in the slot (or the wave's part)
-    static_assert(kPrivate ? 4 * kWaveBytes <= Sh::kSlotBytes : Dy::kBytes + X::kBytes <= Sh::kSlotBytes, "a k-step must fit its slot");
+    static_assert(kPrivate ? (kPair ? 2 : 4) * kWaveBytes <= Sh::kSlotBytes && (kDyFetch + kXFetch) * 1024 <= kWaveBytes
+                           : Dy::kBytes + X::kBytes <= Sh::kSlotBytes, "a k-step must fit its slot");
     static_assert((!Dy::kTiled || kDyFetch % 4 == 0) && (!X::kTiled || kXFetch % 4 == 0),
                   "the waves' shares of a tiled operand are whole and equal");
-    static_assert(!kPrivate || (kDyPerWave <= 4 && kXPerWave <= 4 && Dy::kTiled && X::kTiled), "one DMA call per operand");
+    static_assert(!kPrivate || (kDyPerWave <= 8 && kXPerWave <= 8), "at most two DMA calls per operand");
 };
 
 // part 0: this wave's dY pieces of the step, part 1: its X pieces.  A wave whose share would run
@@ -571,7 +580,12 @@ __device__ __forceinline__ void ring_issue_part(const float* dy, const float* x,
     char* dst = slot + (kPart == 0 ? 0 : P::kXOffset);
     constexpr bool tiled = kPart == 0 ? P::Dy::kTiled : P::X::kTiled;
     static_assert(!tiled || per % 2 == 0 || per == 1, "first piece of a wave even, or single pieces");
-    ring_dma<per, tiled>(src + first * 1024, dst + first * 1024, lane, tiled && per == 1 ? first & 1 : 0);
+    if constexpr (P::kPrivate && per > 4) {               // (a wave's whole operand: 4 pieces, then the rest)
+        ring_dma<4, tiled>(src, dst, lane);
+        ring_dma<per - 4, tiled>(src + 4096, dst + 4096, lane);
+    } else {
+        ring_dma<per, tiled>(src + first * 1024, dst + first * 1024, lane, tiled && per == 1 ? first & 1 : 0);
+    }
 }
 
 struct H2 {                   // an operand as f16 pairs: value = (h + l) / scale
@@ -628,7 +642,7 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     int out0, in0;                                // first 32-wide tile of this wave
     if (Sh::kMap == kMapGrid) { out0 = Sh::kTo * (wave >> 1); in0 = Sh::kTi * (wave & 1); }
     else if (Sh::kMap == kMapRows) { out0 = Sh::kTo * wave; in0 = 0; }
-    else if (Sh::kMap == kMapPrivate) { out0 = 0; in0 = 0; }
+    else if (Sh::kMap == kMapPrivate || Sh::kMap == kMapPrivatePair) { out0 = 0; in0 = 0; }
     else { out0 = 0; in0 = Sh::kTi * wave; }
 
     float ga[Sh::kTi], be[Sh::kTi];
@@ -678,7 +692,9 @@ __device__ __forceinline__ void wgrad_body_ring(const WgradJob& ba, char* smem, 
     const int64_t sample_begin = tile_begin * kKs;
     const int i = lane & 31, kk = lane >> 5;
 
-    auto slot_of = [&](int64_t t) { return smem + (int)(t & (kRingSlots - 1)) * Sh::kSlotBytes + wave * P::kWaveBytes; };
+    auto slot_of = [&](int64_t t) {
+        return smem + (int)(t & (kRingSlots - 1)) * Sh::kSlotBytes + (P::kPair ? wave & 1 : wave) * P::kWaveBytes;
+    };
     auto issue_step = [&](int64_t t) {            // all pieces of step t (prologue)
         ring_issue_part<Sh, 0>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
         ring_issue_part<Sh, 1>(dy, x, sample_begin + t * kRingStep, slot_of(t), wave, lane);
