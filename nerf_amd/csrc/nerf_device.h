@@ -321,6 +321,15 @@ struct ResidentPipe {
     __device__ __forceinline__ void prefetch_next() {}
 };
 
+// relu(x) as an INTEGER maximum on the bits (a negative float is a negative integer, a positive one itself; -0.0 -> +0.0
+// like fmax): one instruction.  fmaxf on a raw MFMA result costs two — the compiler canonicalises the operand first
+// (v_max_f32 x, x, x: it cannot know the accumulator holds no signalling NaN), and so does every other floating-point
+// way of writing it (v_med3, compare + select).
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -119,7 +119,7 @@ __device__ __forceinline__ void relu_layer_norm(const f32x4 (&acc)[16], const fl
     for (int T = 0; T < 16; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float a = __builtin_fmaxf(acc[T][r], 0.f);
+            const float a = relu_bits(acc[T][r]);
             act[4 * T + r] = a;
             sum += a;
             sq = __builtin_fmaf(a, a, sq);
